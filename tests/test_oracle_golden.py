@@ -1,0 +1,123 @@
+"""Pins the CPU oracle (oracle/dff_oracle.c) -- runs on CPU, no GPU needed.
+
+The oracle is the checker for every GPU parity test, so before it is trusted it
+is checked here against
+  * the reference AUTHOR's published gfortran outputs (KAT-A notebook print,
+    KAT-B rays.dat), and
+  * fixtures produced by running the reference source itself
+    (tests/golden/make_golden.py; /root/reference/subroutineR-quiet.f90
+    compiled unmodified with amdflang), and
+  * where oracle/_ref was built (the build container), the live reference on
+    fresh random inputs.
+"""
+import numpy as np
+import pytest
+
+from conftest import compare_times, golden_case_names
+from oracle import oracle as O
+
+
+def test_kat_a_notebook_print(kat):
+    """raytracerR-export-data-to-MCMC.nb.html: print(timeP$timeP) for NSrc=5, 7 printed digits."""
+    m = kat["model"]
+    a = kat["kat_a"]
+    t = O.oracle_dff(m["vels"], m["depths"], a["src_offset"], a["src_depth"])
+    printed = np.array(a["printed_timeP"])
+    assert np.all(np.abs(t - printed) < 0.5e-7)
+    assert [f"{x:.7f}" for x in t] == [f"{x:.7f}" for x in printed]
+    compare_times(t, kat["kat_a_ref_timeP"], tol=1e-12)
+
+
+def test_kat_b_rays_dat(kat):
+    """/root/reference/rays.dat: the author's keep_delta=10 dump of the 20 test_1 rays
+    (subroutineR-quiet.f90:157-164): per ray one record of d_i, one of H_i."""
+    m = kat["model"]
+    off, dep = kat["test_1_src_offset"], kat["test_1_src_depth"]
+    t, p, nl = O.oracle_dff(m["vels"], m["depths"], off, dep, want_p=True)
+    ours = []
+    for k in range(len(off)):
+        d, h = O.oracle_ray_segments(m["vels"], m["depths"], off[k], dep[k], p[k])
+        assert d.size == nl[k]
+        ours += list(d) + list(h)
+    ref = np.array(kat["kat_b"]["rays_dat_tokens"])
+    ours = np.array(ours)
+    assert ours.size == ref.size == 152
+    rel = np.abs(ours - ref) / np.maximum(np.abs(ref), 1e-300)
+    assert rel.max() < 5e-13, rel.max()
+    # the reference stops at |f| < 0.1 m, not at the root: the horizontal miss is visible in its own dump
+    pos = 0
+    for k in range(len(off)):
+        miss = abs(ref[pos:pos + nl[k]].sum() - off[k])
+        assert miss < 0.1
+        pos += 2 * nl[k]
+
+
+def test_config1_test_1(kat):
+    """BASELINE config 1: dff on test_1_src_data.txt with the test_1 model."""
+    m = kat["model"]
+    t = O.oracle_dff(m["vels"], m["depths"], kat["test_1_src_offset"], kat["test_1_src_depth"])
+    err = compare_times(t, kat["config1_ref_timeP"], tol=1e-12)
+    assert err == 0.0  # bit-exact against flang -O2 (plain left-to-right SUM, as gfortran)
+    compare_times(t, kat["config1_ref_timeP_O0"], tol=1e-12)  # flang -O0 uses a compensated SUM()
+    # KAT-C (statistical): the committed observations are forward + N(0, 0.016 s)
+    res = np.array(kat["test_1_obs_RT"]) - t
+    assert abs(res.std() - 0.016) < 0.006 and np.abs(res).max() < 0.05
+
+
+def test_raytracer_r_example(kat):
+    """rayTracerR.R:23-33 on eqdf.csv."""
+    e = kat["rayTracerR_example"]
+    t = O.oracle_dff(e["vels"], e["depths"], e["src_offset"], e["src_depth"])
+    assert compare_times(t, e["ref_timeP"], tol=1e-12) == 0.0
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_reference_fixture(name, golden_batches):
+    c = golden_batches[name]
+    t = O.oracle_dff(c["vels"], c["depths"], c["off"], c["dep"])
+    err = compare_times(t, c["timeP"], tol=1e-12)
+    assert err == 0.0, f"{name}: oracle not bit-exact with the compiled reference ({err:.3e})"
+
+
+def test_loglhood_rt_golden(kat):
+    """loglhood.f90:165-199 on the test_1 MAP model (sd = 0.02): SURVEY.md section 4 value."""
+    m = kat["model"]
+    t = O.oracle_dff(m["vels"], m["depths"], kat["test_1_src_offset"], kat["test_1_src_depth"])
+    g = kat["test_1_map_logL_survey"]
+    ll = O.oracle_loglhood_rt(kat["test_1_obs_RT"], t, g["sd"])
+    assert abs(ll - g["value"]) < 1e-10 * abs(g["value"])
+    ll2 = O.oracle_loglhood_rt(kat["test_1_obs_RT"], t, g["sd"], stable=True)
+    assert abs(ll2 - ll) < 1e-12 * abs(ll)
+
+
+def test_branch_statistics_consistent(kat, golden_index):
+    """The oracle's branch counters add up (every source takes exactly one of the four paths) and the
+    committed index carries them for every fixture (used by DESIGN.md's flop estimate).  The table in
+    SURVEY.md 8(a) came from a differently instrumented copy and is NOT reproduced: the bit-exact
+    travel times above are the pin, not these counters."""
+    m = kat["model"]
+    t, st = O.oracle_dff_stats(m["vels"], m["depths"], kat["test_1_src_offset"], kat["test_1_src_depth"])
+    assert st["top_layer"] + st["cf_negative"] + st["safe_jump"] + st["bisect"] == len(t)
+    assert st["not_conv"] == int((t == -999.0).sum())
+    assert st["fp_evals"] <= st["f_evals"]
+    for c in golden_index:
+        s = c["oracle_branch_stats"]
+        assert s["top_layer"] + s["cf_negative"] + s["safe_jump"] + s["bisect"] == c["nsrc"]
+        assert s["not_conv"] == c["n_sentinel"]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built here (needs /root/reference + amdflang)")
+def test_live_reference_random_models():
+    """Fresh random models against the live compiled reference (build container only)."""
+    rng = np.random.default_rng(20261004)
+    worst = 0.0
+    for it in range(40):
+        k = int(rng.integers(2, 31))
+        d = np.sort(rng.uniform(100.1, 10000.1, k - 1))
+        v = rng.uniform(1500, 10000, k)
+        off = rng.uniform(0, 12000, 3000)
+        dep = rng.uniform(1, 11000, 3000)
+        t = O.oracle_dff(v, d, off, dep)
+        r = O.ref_dff(v, d, off, dep)
+        worst = max(worst, compare_times(t, r, tol=1e-12))
+    assert worst == 0.0
