@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- travel-times/sec of the `dff` forward model on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nsrc 1000000] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md 8(d) "C2"): one `dff` forward over 1e6 synthetic
+sources and an 8-interface / 9-velocity model with one low-velocity zone, fp64, seed 12345.
+A "step" is one pass of the hot path (rtmi_trace_device through the C ABI) over that batch, with
+src_offset / src_depth / the model already resident in HBM and timeP left in HBM.
+
+Multi-GPU (SURVEY.md 8(e), row "single forward"): sources are independent, so every rank traces
+its own 1e6-source shard of the same model -- weak scaling, no data-path collective; the only
+torch.distributed traffic is the timing barrier and the MAX-over-ranks of the elapsed time.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with
+  roofline      HBM view the north_star asks for: 24 algorithmic bytes per travel time
+                (8 B offset + 8 B depth read, 8 B timeP written) / average kernel duration
+                measured with HIP events on the launch stream, against 8 TB/s.  The kernel is
+                fp64-VALU bound, so this fraction is small by construction;
+                `valu_fp64` next to it prices the same launch in executed fp64 flops.
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on the
+                same workload -- baseline only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz
+BYTES_PER_TT = 24.0
+
+
+def c2_workload(n: int, seed: int = 12345, shard: int = 0):
+    """SURVEY.md 8(d) config C2.  shard > 0 draws a different source set for the same model."""
+    rng = np.random.default_rng(seed)
+    d = np.cumsum(rng.uniform(300, 800, 8))
+    v = np.sort(rng.uniform(1500, 6500, 9))
+    v[[2, 3]] = v[[3, 2]]
+    if shard:
+        rng = np.random.default_rng([seed, shard])
+    off = rng.uniform(10, 8000, n)
+    dep = rng.uniform(50, d[-1] + 500, n)
+    return v, d, off, dep
+
+
+def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
+    """Time the CPU restatement on this host: all cores (threads over source slices; the C code
+    holds no shared state and ctypes releases the GIL) and one core.  Bounded to ~budget_s."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+
+    n = off.size
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    O.oracle_dff(v, d, off[:1000], dep[:1000])  # load + warm
+    # single thread, on a sample sized to ~3 s
+    n1 = min(n, 1_000_000)
+    t0 = time.perf_counter()
+    O.oracle_dff(v, d, off[:n1], dep[:n1])
+    t_single = time.perf_counter() - t0
+    single = n1 / t_single
+    # all cores: repeat the full workload until the budget is used
+    nthreads = max(1, cores)
+    bounds = np.linspace(0, n, nthreads * 4 + 1).astype(int)
+
+    def work(i):
+        O.oracle_dff(v, d, off[bounds[i]:bounds[i + 1]], dep[bounds[i]:bounds[i + 1]])
+
+    reps = 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nthreads) as ex:
+        while True:
+            list(ex.map(work, range(nthreads * 4)))
+            reps += 1
+            if time.perf_counter() - t0 > budget_s - t_single or reps >= 200:
+                break
+    t_all = time.perf_counter() - t0
+    out = {"value": reps * n / t_all, "unit": "travel-times/s", "cores": nthreads, "kind": "port",
+           "sample": f"{reps} x the full {n}-source C2 workload, {nthreads} threads over source slices "
+                     f"(oracle/dff_oracle.c, gcc -O2 -ffp-contract=off)",
+           "single_thread_value": single}
+    # the reference's own Fortran (oracle/_ref, built in the build container), one core
+    if O.have_ref():
+        try:
+            t0 = time.perf_counter()
+            O.ref_dff(v, d, off[:n1], dep[:n1])
+            out["reference_single_thread_value"] = n1 / (time.perf_counter() - t0)
+            out["reference_build"] = "subroutineR-quiet.f90, amdflang -O2 (oracle/Makefile)"
+        except Exception as e:  # pragma: no cover
+            out["reference_error"] = str(e)
+    return out
+
+
+def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None, stream=None):
+    """The timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a
+    device synchronise on both sides; returns (max-over-ranks wall seconds, max-over-ranks average
+    per-launch milliseconds from HIP events recorded on the launch stream, or None without events).
+    `dist` is torch.distributed (initialised) or None; works with gloo on CPU for the tests."""
+    import torch
+
+    def barrier():
+        if dist is not None and world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    ev0 = ev1 = None
+    if make_event is not None:
+        ev0, ev1 = make_event(), make_event()
+    sync()
+    t0 = time.perf_counter()
+    if ev0 is not None:
+        ev0.record(stream)
+    for _ in range(steps):
+        step()
+    if ev1 is not None:
+        ev1.record(stream)
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / steps if ev0 is not None else -1.0
+    if dist is not None and world > 1:
+        tt = torch.tensor([elapsed, kern_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(tt[0]), float(tt[1])
+    return elapsed, (kern_ms if kern_ms >= 0 else None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nsrc", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import raytracerfortran_amd as rt
+    rt.load_library()
+    rt.init(local_rank)
+
+    n = args.nsrc
+    v, d, off, dep = c2_workload(n, shard=rank)
+    dv, dd = torch.tensor(v, device=dev), torch.tensor(d, device=dev)
+    do, dz = torch.tensor(off, device=dev), torch.tensor(dep, device=dev)
+    dt = torch.empty(n, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rt.trace_device(dv, dd, do, dz, timeP=dt, stream=stream)
+
+    elapsed, kern_ms = timed_steps(step, args.steps, args.warmup, world, dist if world > 1 else None, dev,
+                                   sync=torch.cuda.synchronize,
+                                   make_event=lambda: torch.cuda.Event(enable_timing=True), stream=stream)
+
+    check = None
+    if args.check and rank == 0:
+        from oracle import oracle as O
+        ref = O.oracle_dff(v, d, off, dep)
+        got = dt.cpu().numpy()
+        okm = ref != -999.0
+        check = {"max_abs_dt": float(np.abs(got[okm] - ref[okm]).max()),
+                 "sentinel_mismatch": int(((got == -999.0) != (ref == -999.0)).sum())}
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        achieved = BYTES_PER_TT * n / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: single dff forward, 1e6 sources x 8 interfaces (9 velocities, one LVZ), "
+                                   "seed 12345; BASELINE.json configs[1]",
+                       "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rtmi::trace_kernel<false,true,false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
+                         "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; "
+                                 "see DESIGN.md"},
+        }
+        if check is not None:
+            res["check_vs_oracle"] = check
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(v, d, off, dep)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * rtmi.h -- C ABI of librtmi.so: the MI355X (gfx950) implementation of the
+ * 1-D layered-earth first-arrival travel-time forward model of
+ * AntonBiryukovUofC/RayTracerFortran (module raymod).
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * /root/reference).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions shared by all entry points (they are the reference's):
+ *   vels[nlayers+1]  P velocity of each layer, top -> down, last = half-space, m/s
+ *   depths[nlayers]  depth TO each interface (not thicknesses), m
+ *   src_offset[n]    horizontal source-receiver distance, m
+ *   src_depth[n]     source depth, m
+ *   timeP[n]         out: travel time, s; -999 where the reference's solver
+ *                    reports non-convergence (subroutineR-quiet.f90:167-169)
+ * All arithmetic is IEEE fp64 in the reference's operation order.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_VERSION 100      /* 0.1.0 */
+#define RTMI_MAX_LAYERS 1024  /* interfaces per model the kernels accept */
+
+/* Status codes of the rtmi_* entry points (0 = success). */
+enum {
+    RTMI_OK = 0,
+    RTMI_ERR_NO_DEVICE = 1,   /* no usable gfx950 device / HIP runtime failure at init */
+    RTMI_ERR_BAD_ARG = 2,     /* nlayers < 1, nlayers > RTMI_MAX_LAYERS, negative counts, NULL pointers */
+    RTMI_ERR_HIP = 3,         /* a HIP call failed; text in rtmi_last_error() */
+    RTMI_ERR_IO = 4           /* rays.dat could not be written */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Drop-in symbols: host pointers in, host pointers out.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces `subroutine dofullforwardproblem(...) bind(C, name="dff_")`,
+ * subroutineR-quiet.f90:408-463 -- the symbol R's
+ *   .Fortran("dff", vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, keep_delta)
+ * resolves (rayTracerR.R:31-33).  All arguments by reference, as Fortran passes them.
+ * keep_delta > 0 additionally writes ./rays.dat (two records per ray: horizontal
+ * segment lengths, then segment thicknesses; subroutineR-quiet.f90:98-105,157-164).
+ * No status is returned (the reference has none): on a device failure the call
+ * prints the reason to stderr, fills timeP with NaN and aborts the process unless
+ * RTMI_ABORT_ON_ERROR=0 is set in the environment.
+ */
+void dff_(const double *vels, const double *depths, const int *NLayers, double *src_offset,
+          double *src_depth, const int *NSrc, double *timeP, const int *keep_delta);
+
+/*
+ * Replaces the body of `subroutine TraceRays(...)`, subroutineR-quiet.f90:467-520
+ * (sampler copy ray_tracing_sampling/subroutineR-quiet.f90:459), called by
+ * LOGLHOOD_RT (loglhood.f90:135,144).  TraceRays is a Fortran MODULE procedure,
+ * so its link name is compiler specific; shim/raymod.f90 provides `module raymod`
+ * whose TraceRays forwards here.  Same argument meaning as dff_.
+ */
+void rtmi_tracerays(const double *vels, const double *depths, const int *NLayers, double *src_offset,
+                    double *src_depth, const int *NSrc, double *timeP, const int *keep_delta);
+
+/*
+ * 7-argument flavour: `dff_` of subroutineR.f90:405 (no keep_delta), the one
+ * README.md:16-21 and adaptMCMC.Rmd:74-78 call.  Exported under its own name
+ * here; librtmi_dff7.so re-exports it as `dff_` for callers that load that file.
+ */
+void rtmi_dff7(const double *vels, const double *depths, const int *NLayers, double *src_offset,
+               double *src_depth, const int *NSrc, double *timeP);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Library state.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bind the calling process to HIP device `device` (default 0 if never called). */
+int rtmi_init(int device);
+/* Text of the last error of the calling thread ("" if none). */
+const char *rtmi_last_error(void);
+int rtmi_version(void);
+/* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
+int rtmi_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Device-resident entry points: every pointer is a DEVICE pointer, `stream`
+ *    is a hipStream_t (NULL = default stream).  Nothing is allocated, copied or
+ *    synchronised: the launch is asynchronous and graph-capturable.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * One forward evaluation: the loop body of dff_/TraceRays
+ * (subroutineR-quiet.f90:434-462: whichLayer, InsertLayer, GetPTime) for nsrc
+ * sources of one model.  d_p_final may be NULL; when given it receives the final
+ * ray parameter of each source (NaN for straight top-layer rays), from which the
+ * rays.dat records are rebuilt on the host.
+ */
+int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
+                      const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                      double *d_timeP, double *d_p_final, void *stream);
+
+/*
+ * Many models over one shared source set: what nmodels consecutive calls of
+ * TraceRays from LOGLHOOD_RT compute (loglhood.f90:128-146), in one launch.
+ *   d_vels   [nmodels][ld_model]   row m holds nlayers[m]+1 velocities
+ *   d_depths [nmodels][ld_model]   row m holds nlayers[m] interface depths
+ *   d_nlayers[nmodels]             int32, each in [1, RTMI_MAX_LAYERS]
+ *   d_timeP  [nmodels][nsrc]       may be NULL when only logL is wanted
+ * Optional fused Gaussian log-likelihood (loglhood.f90:165-199, ICOV = 1, one mode):
+ *   d_obs[nsrc], d_sd[nmodels] -> d_logL[nmodels]; pass NULL for all three to skip.
+ *   d_work: >= rtmi_trace_batch_work_bytes(nmodels, nsrc) bytes of scratch.
+ * logL uses -(N/2) ln(2 pi) for the normalisation, which equals the reference's
+ * LOG(1/(2 pi)**(N/2)) wherever that expression does not overflow (N < ~770).
+ */
+int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const int32_t *d_nlayers,
+                            int ld_model, int nmodels, const double *d_src_offset,
+                            const double *d_src_depth, int64_t nsrc, double *d_timeP,
+                            const double *d_obs, const double *d_sd, double *d_logL, void *d_work,
+                            void *stream);
+int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Host-side helpers of the drop-in path.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Write the reference's rays.dat (subroutineR-quiet.f90:98-105,157-164) for
+ * sources whose final ray parameters are known.  One record per line, values
+ * separated by blanks, as MiscFunctions.R:13-26 (read.rays) parses them.
+ */
+int rtmi_write_rays_dat(const char *path, const double *vels, const double *depths, int nlayers,
+                        const double *src_offset, const double *src_depth, const double *p_final,
+                        int64_t nsrc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,430 @@
+// rtmi_capi.cpp -- the C ABI of librtmi.so (include/rtmi.h).
+//
+// Host side of the drop-in boundary: owns the per-process device context, moves
+// the caller's host buffers to HBM and back for the reference-shaped entry points
+// (dff_, rtmi_tracerays, rtmi_dff7), and validates + forwards the device-resident
+// entry points to the launchers in rtmi_kernels.hip.  There is NO CPU fallback:
+// if the GPU path cannot run, the call fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "rtmi_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RTMI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
+    } while (0)
+
+// Per-process context of the host-pointer entry points.
+struct Context {
+    std::mutex mu;
+    bool ready = false;
+    int device = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    // grow-only device buffers of the drop-in path
+    double *d_model = nullptr;  // vels | depths
+    size_t model_cap = 0;
+    double *d_src = nullptr;    // offset | depth | timeP | p_final
+    size_t src_cap = 0;
+};
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+int ensure_ready_locked(Context &c)
+{
+    if (c.ready)
+        return RTMI_OK;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(RTMI_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (c.device >= ndev)
+        return fail(RTMI_ERR_NO_DEVICE, "device %d requested, %d visible", c.device, ndev);
+    HIP_TRY(hipSetDevice(c.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c.device));
+    c.cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.ready = true;
+    return RTMI_OK;
+}
+
+int grow(double **p, size_t *cap, size_t need)
+{
+    if (need <= *cap)
+        return RTMI_OK;
+    if (*p)
+        HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = need + need / 4 + 1024;
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(double)));
+    *cap = n;
+    return RTMI_OK;
+}
+
+int check_model(int nlayers)
+{
+    if (nlayers < 1 || nlayers > RTMI_MAX_LAYERS)
+        return fail(RTMI_ERR_BAD_ARG, "nlayers = %d outside [1, %d]", nlayers, RTMI_MAX_LAYERS);
+    return RTMI_OK;
+}
+
+int num_cus_for_current_device()
+{
+    Context &c = ctx();
+    if (c.cus > 0)
+        return c.cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return 256;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 256;
+    return cus;
+}
+
+// The reference-shaped call: host buffers in, host buffers out, optional rays.dat.
+int trace_host(const double *vels, const double *depths, int nlayers, const double *src_offset,
+               const double *src_depth, int nsrc, double *timeP, int keep_delta)
+{
+    if (!vels || !depths || (nsrc > 0 && (!src_offset || !src_depth || !timeP)))
+        return fail(RTMI_ERR_BAD_ARG, "NULL argument");
+    if (nsrc < 0)
+        return fail(RTMI_ERR_BAD_ARG, "NSrc = %d < 0", nsrc);
+    int rc = check_model(nlayers);
+    if (rc)
+        return rc;
+    if (nsrc == 0)
+        return RTMI_OK;
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = ensure_ready_locked(c);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(c.device));
+    const bool want_p = keep_delta > 0;
+    const size_t n = (size_t)nsrc;
+    rc = grow(&c.d_model, &c.model_cap, (size_t)2 * nlayers + 1);
+    if (rc)
+        return rc;
+    rc = grow(&c.d_src, &c.src_cap, 4 * n);
+    if (rc)
+        return rc;
+    double *d_vels = c.d_model, *d_depths = c.d_model + nlayers + 1;
+    double *d_off = c.d_src, *d_dep = c.d_src + n, *d_t = c.d_src + 2 * n, *d_p = c.d_src + 3 * n;
+    HIP_TRY(hipMemcpyAsync(d_vels, vels, (size_t)(nlayers + 1) * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(d_depths, depths, (size_t)nlayers * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(d_off, src_offset, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(d_dep, src_depth, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    rc = rtmi_trace_device(d_vels, d_depths, nlayers, d_off, d_dep, nsrc, d_t, want_p ? d_p : nullptr, c.stream);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(timeP, d_t, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    std::vector<double> p;
+    if (want_p) {
+        p.resize(n);
+        HIP_TRY(hipMemcpyAsync(p.data(), d_p, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    if (want_p)
+        return rtmi_write_rays_dat("rays.dat", vels, depths, nlayers, src_offset, src_depth, p.data(), nsrc);
+    return RTMI_OK;
+}
+
+// The reference API has no status channel: fail loudly.
+void dropin_failed(const char *who, double *timeP, int nsrc)
+{
+    fprintf(stderr, "librtmi: %s failed: %s\n", who, g_err.c_str());
+    if (timeP)
+        for (int i = 0; i < nsrc; ++i)
+            timeP[i] = NAN;
+    const char *e = getenv("RTMI_ABORT_ON_ERROR");
+    if (!e || strcmp(e, "0") != 0)
+        abort();
+}
+
+// gfortran list-directed REAL(8): 17 significant digits, F form for 0.1 <= |x| < 1e17, else E form.
+void format_real(char *out, size_t cap, double x)
+{
+    const double ax = fabs(x);
+    if (x == 0.0) {
+        snprintf(out, cap, "%21s     ", "0.0000000000000000");
+        return;
+    }
+    if (std::isfinite(x) && ax >= 0.1 && ax < 1e17) {
+        int int_digits = (ax < 1.0) ? 0 : (int)floor(log10(ax)) + 1;
+        int dec = 17 - int_digits;
+        if (dec < 0)
+            dec = 0;
+        char num[64];
+        snprintf(num, sizeof num, "%.*f", dec, x);
+        // rounding may have added a digit (9.99.. -> 10.0..): recompute once
+        int int_digits2 = 0;
+        for (const char *q = (num[0] == '-') ? num + 1 : num; *q && *q != '.'; ++q)
+            ++int_digits2;
+        if (ax >= 1.0 && int_digits2 != int_digits) {
+            dec = 17 - int_digits2;
+            if (dec < 0)
+                dec = 0;
+            snprintf(num, sizeof num, "%.*f", dec, x);
+        }
+        snprintf(out, cap, "%21s     ", num);
+    } else {
+        char num[64];
+        snprintf(num, sizeof num, "%.16E", x);
+        snprintf(out, cap, "%26s", num);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtmi_version(void) { return RTMI_VERSION; }
+
+const char *rtmi_last_error(void) { return g_err.c_str(); }
+
+int rtmi_init(int device)
+{
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.ready && c.device != device) {
+        // rebind: drop the old context's buffers
+        (void)hipSetDevice(c.device);
+        if (c.d_model)
+            (void)hipFree(c.d_model);
+        if (c.d_src)
+            (void)hipFree(c.d_src);
+        if (c.stream)
+            (void)hipStreamDestroy(c.stream);
+        c.d_model = c.d_src = nullptr;
+        c.model_cap = c.src_cap = 0;
+        c.stream = nullptr;
+        c.cus = 0;
+        c.ready = false;
+    }
+    c.device = device;
+    return ensure_ready_locked(c);
+}
+
+int rtmi_device_cus(void)
+{
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (ensure_ready_locked(c) != RTMI_OK)
+        return 0;
+    return c.cus;
+}
+
+int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
+                      const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final, void *stream)
+{
+    int rc = check_model(nlayers);
+    if (rc)
+        return rc;
+    if (nsrc < 0)
+        return fail(RTMI_ERR_BAD_ARG, "nsrc < 0");
+    if (nsrc == 0)
+        return RTMI_OK;
+    if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
+        return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
+    rtmi::TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.d_vels = d_vels;
+    a.d_depths = d_depths;
+    a.d_nlayers = nullptr;
+    a.nlayers = nlayers;
+    a.ld_model = 0;
+    a.d_src_offset = d_src_offset;
+    a.d_src_depth = d_src_depth;
+    a.nsrc = nsrc;
+    a.d_timeP = d_timeP;
+    a.d_p_final = d_p_final;
+    const int gx = rtmi_launch_grid_x(nsrc, 1, num_cus_for_current_device());
+    HIP_TRY(rtmi_launch_trace(&a, 1, nlayers, gx, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc)
+{
+    if (nmodels < 1 || nsrc < 0)
+        return 0;
+    const int gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
+    return (int64_t)nmodels * gx * (int64_t)sizeof(double);
+}
+
+int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model,
+                            int nmodels, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                            double *d_timeP, const double *d_obs, const double *d_sd, double *d_logL, void *d_work,
+                            void *stream)
+{
+    if (nmodels < 0 || nsrc < 0)
+        return fail(RTMI_ERR_BAD_ARG, "negative count");
+    if (nmodels == 0 || nsrc == 0)
+        return RTMI_OK;
+    if (ld_model < 2 || ld_model - 1 > RTMI_MAX_LAYERS)
+        return fail(RTMI_ERR_BAD_ARG, "ld_model = %d outside [2, %d]", ld_model, RTMI_MAX_LAYERS + 1);
+    if (nmodels > 65535)
+        return fail(RTMI_ERR_BAD_ARG, "nmodels = %d > 65535 (grid.y)", nmodels);
+    if (!d_vels || !d_depths || !d_nlayers || !d_src_offset || !d_src_depth)
+        return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
+    const bool want_ll = d_obs || d_sd || d_logL;
+    if (want_ll && (!d_obs || !d_sd || !d_logL || !d_work))
+        return fail(RTMI_ERR_BAD_ARG, "logL needs d_obs, d_sd, d_logL and d_work together");
+    if (!want_ll && !d_timeP)
+        return fail(RTMI_ERR_BAD_ARG, "nothing to compute: d_timeP and d_logL both NULL");
+    rtmi::TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.d_vels = d_vels;
+    a.d_depths = d_depths;
+    a.d_nlayers = d_nlayers;
+    a.nlayers = 0;
+    a.ld_model = ld_model;
+    a.d_src_offset = d_src_offset;
+    a.d_src_depth = d_src_depth;
+    a.nsrc = nsrc;
+    a.d_timeP = d_timeP;
+    a.d_p_final = nullptr;
+    a.d_obs = want_ll ? d_obs : nullptr;
+    a.d_partial = (double *)d_work;
+    const int gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
+    HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, (hipStream_t)stream));
+    if (want_ll)
+        HIP_TRY(rtmi_launch_loglike((const double *)d_work, gx, d_sd, nsrc, nmodels, d_logL, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+void dff_(const double *vels, const double *depths, const int *NLayers, double *src_offset, double *src_depth,
+          const int *NSrc, double *timeP, const int *keep_delta)
+{
+    if (!NLayers || !NSrc) {
+        fail(RTMI_ERR_BAD_ARG, "NULL NLayers/NSrc");
+        dropin_failed("dff_", nullptr, 0);
+        return;
+    }
+    const int kd = keep_delta ? *keep_delta : -1;
+    if (trace_host(vels, depths, *NLayers, src_offset, src_depth, *NSrc, timeP, kd) != RTMI_OK)
+        dropin_failed("dff_", timeP, *NSrc);
+}
+
+void rtmi_tracerays(const double *vels, const double *depths, const int *NLayers, double *src_offset,
+                    double *src_depth, const int *NSrc, double *timeP, const int *keep_delta)
+{
+    if (!NLayers || !NSrc) {
+        fail(RTMI_ERR_BAD_ARG, "NULL NLayers/NSrc");
+        dropin_failed("TraceRays", nullptr, 0);
+        return;
+    }
+    const int kd = keep_delta ? *keep_delta : -1;
+    if (trace_host(vels, depths, *NLayers, src_offset, src_depth, *NSrc, timeP, kd) != RTMI_OK)
+        dropin_failed("TraceRays", timeP, *NSrc);
+}
+
+void rtmi_dff7(const double *vels, const double *depths, const int *NLayers, double *src_offset, double *src_depth,
+               const int *NSrc, double *timeP)
+{
+    if (!NLayers || !NSrc) {
+        fail(RTMI_ERR_BAD_ARG, "NULL NLayers/NSrc");
+        dropin_failed("dff_ (7-argument)", nullptr, 0);
+        return;
+    }
+    if (trace_host(vels, depths, *NLayers, src_offset, src_depth, *NSrc, timeP, -1) != RTMI_OK)
+        dropin_failed("dff_ (7-argument)", timeP, *NSrc);
+}
+
+int rtmi_write_rays_dat(const char *path, const double *vels, const double *depths, int nlayers,
+                        const double *src_offset, const double *src_depth, const double *p_final, int64_t nsrc)
+{
+    int rc = check_model(nlayers);
+    if (rc)
+        return rc;
+    FILE *fp = fopen(path, "w");  // status='REPLACE'  (subroutineR-quiet.f90:432)
+    if (!fp)
+        return fail(RTMI_ERR_IO, "cannot open %s for writing", path);
+    std::vector<double> d((size_t)nlayers + 1), h((size_t)nlayers + 1);
+    char cell[64];
+    for (int64_t k = 0; k < nsrc; ++k) {
+        const double z = src_depth[k];
+        // whichLayer (:9-32)
+        int nl = 0;
+        double diff = 0.0;
+        for (int i = 1; i <= nlayers; ++i) {
+            nl = i;
+            diff = depths[i - 1] - z;
+            if (diff > 0.0)
+                break;
+        }
+        if (diff < 0.0)
+            nl = nlayers + 1;
+        int nseg;
+        if (nl == 1) {
+            // :98-105 -- `d` has nl_src = 1 element = the offset; then the source depth
+            d[0] = src_offset[k];
+            h[0] = z;
+            nseg = 1;
+        } else {
+            const double p = p_final[k];
+            for (int i = 0; i < nl; ++i) {
+                double Hi;
+                if (i == 0)
+                    Hi = depths[0];
+                else if (i < nl - 1)
+                    Hi = depths[i] - depths[i - 1];
+                else
+                    Hi = z - depths[nl - 2];
+                const double cosv = sqrt(1.0 - (p * p) * (vels[i] * vels[i]));
+                const double q = Hi / cosv;
+                d[i] = sqrt(q * q - Hi * Hi);  // :158
+                h[i] = Hi;
+            }
+            nseg = nl;
+        }
+        for (int i = 0; i < nseg; ++i) {
+            format_real(cell, sizeof cell, d[i]);
+            fputs(cell, fp);
+        }
+        fputc('\n', fp);
+        for (int i = 0; i < nseg; ++i) {
+            format_real(cell, sizeof cell, h[i]);
+            fputs(cell, fp);
+        }
+        fputc('\n', fp);
+    }
+    if (fclose(fp) != 0)
+        return fail(RTMI_ERR_IO, "error closing %s", path);
+    return RTMI_OK;
+}
+
+}  // extern "C"

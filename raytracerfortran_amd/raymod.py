@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference's `module raymod` call boundary, over librtmi.so.
+
+The reference is called in two ways:
+
+  R        .Fortran("dff", vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, keep_delta)
+           (/root/reference/rayTracerR.R:31-33) -> C symbol `dff_`,
+           /root/reference/subroutineR-quiet.f90:408
+  Fortran  CALL TraceRays(vels, thickness, k-1, src_offset, src_depth, NSRC, DpredRT, -1)
+           (/root/reference/ray_tracing_sampling/loglhood.f90:135) ->
+           /root/reference/subroutineR-quiet.f90:467
+
+`dff` and `TraceRays` below take the same arguments with the same meaning and go
+through exactly those C symbols of librtmi.so (host buffers in and out), so the
+parity tests read like the reference's own calls.  `trace_device` /
+`trace_batch_device` are the device-resident entry points (HBM in, HBM out; torch
+tensors are used only as owners of device memory and streams).
+
+There is no CPU fallback: if librtmi.so is missing or the GPU path fails, these
+functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtmi.so")
+LIB7_PATH = os.path.join(_HERE, "librtmi_dff7.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+# Every symbol include/rtmi.h declares: (restype, argtypes).  tests/test_boundary.py
+# checks this table against the header and the built library.
+SIGNATURES = {
+    "dff_": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp, _ip]),
+    "rtmi_tracerays": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp, _ip]),
+    "rtmi_dff7": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp]),
+    "rtmi_init": (ctypes.c_int, [ctypes.c_int]),
+    "rtmi_last_error": (ctypes.c_char_p, []),
+    "rtmi_version": (ctypes.c_int, []),
+    "rtmi_device_cus": (ctypes.c_int, []),
+    "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    "rtmi_trace_batch_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64,
+                                               _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
+    "rtmi_write_rays_dat": (ctypes.c_int, [ctypes.c_char_p, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int64]),
+}
+
+_lib = None
+
+
+class RtmiError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen librtmi.so and bind the C ABI.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RtmiError(f"{p} not found: build it with `python -m raytracerfortran_amd.build` "
+                        "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().rtmi_last_error().decode("utf-8", "replace")
+        raise RtmiError(f"librtmi error {rc}: {msg}")
+
+
+def init(device: int = 0) -> None:
+    _check(load_library().rtmi_init(int(device)))
+
+
+def _as_f64(a, n=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size < n:
+        raise ValueError(f"{name} has {a.size} elements, needs {n}")
+    return a
+
+
+def _host_call(symbol, vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, keep_delta):
+    lib = load_library()
+    NLayers = int(NLayers)
+    NSrc = int(NSrc)
+    vels = _as_f64(vels, NLayers + 1, "vels")
+    depths = _as_f64(depths, NLayers, "depths")
+    # .Fortran hands the callee copies of every vector and returns the (modified) copies
+    off = _as_f64(src_offset, NSrc, "src_offset").copy()
+    dep = _as_f64(src_depth, NSrc, "src_depth").copy()
+    t = _as_f64(timeP if timeP is not None else np.zeros(NSrc), NSrc, "timeP").copy()
+    nl, ns = ctypes.c_int(NLayers), ctypes.c_int(NSrc)
+    args = [vels.ctypes.data_as(_dp), depths.ctypes.data_as(_dp), ctypes.byref(nl), off.ctypes.data_as(_dp),
+            dep.ctypes.data_as(_dp), ctypes.byref(ns), t.ctypes.data_as(_dp)]
+    if keep_delta is not None:
+        kd = ctypes.c_int(int(keep_delta))
+        args.append(ctypes.byref(kd))
+    # a device failure inside the void drop-in symbols aborts the process by design; ask for the
+    # NaN-fill instead so that Python can raise
+    old = os.environ.get("RTMI_ABORT_ON_ERROR")
+    os.environ["RTMI_ABORT_ON_ERROR"] = "0"
+    try:
+        getattr(lib, symbol)(*args)
+    finally:
+        if old is None:
+            os.environ.pop("RTMI_ABORT_ON_ERROR", None)
+        else:
+            os.environ["RTMI_ABORT_ON_ERROR"] = old
+    if NSrc > 0 and np.isnan(t[:NSrc]).all():
+        msg = lib.rtmi_last_error().decode("utf-8", "replace")
+        if msg:
+            raise RtmiError(f"{symbol} failed: {msg}")
+    out = {"vels": vels, "depths": depths, "NLayers": NLayers, "src_offset": off, "src_depth": dep, "NSrc": NSrc,
+           "timeP": t}
+    if keep_delta is not None:
+        out["keep_delta"] = int(keep_delta)
+    return out
+
+
+def dff(vels, depths, NLayers, src_offset, src_depth, NSrc, timeP=None, keep_delta=-1):
+    """R's `.Fortran("dff", vels=, depths=, NLayers=, src_offset=, src_depth=, NSrc=, timeP=, keep_delta=)`
+    (rayTracerR.R:31-33).  Returns the same named list (a dict); `["timeP"]` holds the travel times.
+    keep_delta > 0 also writes ./rays.dat like the reference."""
+    return _host_call("dff_", vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, keep_delta)
+
+
+def dff7(vels, depths, NLayers, src_offset, src_depth, NSrc, timeP=None):
+    """The 7-argument `dff` of subroutineR.f90:405 (README.md:16-21, adaptMCMC.Rmd:74-78)."""
+    return _host_call("rtmi_dff7", vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, None)
+
+
+def TraceRays(vels, depths, NLayers, src_offset, src_depth, NSrc, timeP=None, keep_delta=-1):
+    """`CALL TraceRays(vels, depths, NLayers, src_offset, src_depth, NSrc, timeP, keep_delta)`
+    (subroutineR-quiet.f90:467; loglhood.f90:135).  Returns timeP (the INTENT(OUT) argument)."""
+    return _host_call("rtmi_tracerays", vels, depths, NLayers, src_offset, src_depth, NSrc, timeP,
+                      keep_delta)["timeP"]
+
+
+dofullforwardproblem = dff  # the Fortran-side name of `dff_` (subroutineR-quiet.f90:408)
+
+
+def write_rays_dat(path, vels, depths, src_offset, src_depth, p_final) -> None:
+    lib = load_library()
+    vels, depths = _as_f64(vels), _as_f64(depths)
+    off, dep, p = _as_f64(src_offset), _as_f64(src_depth), _as_f64(p_final)
+    _check(lib.rtmi_write_rays_dat(os.fsencode(path), vels.ctypes.data_as(_dp), depths.ctypes.data_as(_dp),
+                                   depths.size, off.ctypes.data_as(_dp), dep.ctypes.data_as(_dp),
+                                   p.ctypes.data_as(_dp), off.size))
+
+
+# ---------------------------------------------------------------------------------------------
+# Device-resident entry points.  Tensors are torch CUDA(=HIP) float64 tensors; only their
+# data_ptr() crosses the boundary.
+# ---------------------------------------------------------------------------------------------
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    import torch
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live in HBM")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, stream=None):
+    """One forward evaluation on resident data (rtmi_trace_device).  Asynchronous on `stream`
+    (default: torch's current stream).  Returns timeP."""
+    import torch
+    lib = load_library()
+    nlayers = int(depths.numel())
+    if vels.numel() != nlayers + 1:
+        raise ValueError("vels must have NLayers+1 elements")
+    n = int(src_offset.numel())
+    if src_depth.numel() != n:
+        raise ValueError("src_offset / src_depth size mismatch")
+    if timeP is None:
+        timeP = torch.empty(n, dtype=torch.float64, device=src_offset.device)
+    if timeP.numel() < n or (p_final is not None and p_final.numel() < n):
+        raise ValueError("output too small")
+    f64 = torch.float64
+    _check(lib.rtmi_trace_device(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers,
+                                 _ptr(src_offset, f64, "src_offset"), _ptr(src_depth, f64, "src_depth"), n,
+                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"), _stream_ptr(stream)))
+    return timeP
+
+
+def trace_batch_device(vels, depths, nlayers, src_offset, src_depth, timeP=None, obs=None, sd=None,
+                       want_timeP=True, stream=None):
+    """Many models over shared sources (rtmi_trace_batch_device).
+
+    vels, depths: [nmodels, ld] float64 (row m: nlayers[m]+1 velocities / nlayers[m] depths);
+    nlayers: [nmodels] int32.  With obs [nsrc] and sd [nmodels] also returns logL [nmodels]
+    (loglhood.f90:165-199).  Returns (timeP or None, logL or None).
+    """
+    import torch
+    lib = load_library()
+    nmodels, ld = int(vels.shape[0]), int(vels.shape[1])
+    if tuple(depths.shape) != (nmodels, ld) or nlayers.numel() != nmodels:
+        raise ValueError("vels/depths/nlayers shape mismatch")
+    n = int(src_offset.numel())
+    dev = src_offset.device
+    f64 = torch.float64
+    if want_timeP and timeP is None:
+        timeP = torch.empty((nmodels, n), dtype=f64, device=dev)
+    if timeP is not None and timeP.numel() < nmodels * n:
+        raise ValueError("timeP too small")
+    logL = work = None
+    if obs is not None:
+        if sd is None or sd.numel() != nmodels or obs.numel() != n:
+            raise ValueError("obs/sd shape mismatch")
+        logL = torch.empty(nmodels, dtype=f64, device=dev)
+        wb = int(lib.rtmi_trace_batch_work_bytes(nmodels, n))
+        work = torch.empty(max(wb // 8, 1), dtype=f64, device=dev)
+        if stream is not None:
+            work.record_stream(stream)
+    _check(lib.rtmi_trace_batch_device(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"),
+                                       _ptr(nlayers, torch.int32, "nlayers"), ld, nmodels,
+                                       _ptr(src_offset, f64, "src_offset"), _ptr(src_depth, f64, "src_depth"), n,
+                                       _ptr(timeP, f64, "timeP"), _ptr(obs, f64, "obs"), _ptr(sd, f64, "sd"),
+                                       _ptr(logL, f64, "logL"), _ptr(work, f64, "work"), _stream_ptr(stream)))
+    return timeP, logL

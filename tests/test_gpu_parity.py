@@ -1,0 +1,264 @@
+"""Parity of the HIP path with the oracle / the reference fixtures -- needs an MI355X.
+
+Everything here calls through the C ABI of librtmi.so (via the ctypes mirror
+raytracerfortran_amd.raymod).  The bar (BASELINE.json): identical -999 sentinel
+positions and |dt| < 1e-9 s in fp64; because the kernel repeats the reference's
+operation order with correctly rounded sqrt and divide, the results are in fact
+expected to be BIT-IDENTICAL, and the tests that say so assert err == 0.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import compare_times, golden_case_names
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9  # seconds; BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracerfortran_amd as r
+    r.load_library()
+    r.init(0)
+    return r
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def c2_workload(n, seed=12345):
+    """8 interfaces, 9 velocities with one LVZ."""
+    rng = np.random.default_rng(seed)
+    d = np.cumsum(rng.uniform(300, 800, 8))
+    v = np.sort(rng.uniform(1500, 6500, 9))
+    v[[2, 3]] = v[[3, 2]]
+    off = rng.uniform(10, 8000, n)
+    dep = rng.uniform(50, d[-1] + 500, n)
+    return v, d, off, dep
+
+
+# ------------------------------------------------------------------------------------------
+# the reference's own example and the author's known answers, through `dff_`
+# ------------------------------------------------------------------------------------------
+def test_config1_test_1(rt, kat):
+    m = kat["model"]
+    r = rt.dff(vels=m["vels"], depths=m["depths"], NLayers=len(m["depths"]),
+               src_offset=kat["test_1_src_offset"], src_depth=kat["test_1_src_depth"],
+               NSrc=len(kat["test_1_src_depth"]), timeP=np.zeros(20), keep_delta=-1)
+    assert compare_times(r["timeP"], kat["config1_ref_timeP"], TOL) == 0.0
+
+
+def test_kat_a_notebook_print(rt, kat):
+    m, a = kat["model"], kat["kat_a"]
+    t = rt.dff(m["vels"], m["depths"], 6, a["src_offset"], a["src_depth"], 5)["timeP"]
+    assert [f"{x:.7f}" for x in t] == [f"{x:.7f}" for x in a["printed_timeP"]]
+
+
+def test_kat_b_rays_dat(rt, kat, tmp_path):
+    """keep_delta = 10 writes ./rays.dat; its token stream must equal the author's committed file."""
+    m = kat["model"]
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        rt.dff(m["vels"], m["depths"], 6, kat["test_1_src_offset"], kat["test_1_src_depth"], 20, keep_delta=10)
+        lines = open("rays.dat").read().splitlines()
+    finally:
+        os.chdir(old)
+    assert len(lines) == 40  # one record per line (read.rays scans line-wise, MiscFunctions.R:13-26)
+    ours = np.array([float(x) for ln in lines for x in ln.split()])
+    ref = np.array(kat["kat_b"]["rays_dat_tokens"])
+    assert ours.size == ref.size
+    assert (np.abs(ours - ref) / np.abs(ref)).max() < 5e-13
+
+
+def test_raytracer_r_example(rt, kat):
+    e = kat["rayTracerR_example"]
+    t = rt.dff(e["vels"], e["depths"], 2, e["src_offset"], e["src_depth"], len(e["src_depth"]), keep_delta=-1)
+    assert compare_times(t["timeP"], e["ref_timeP"], TOL) == 0.0
+
+
+def test_tracerays_and_7arg_flavours(rt, kat):
+    m = kat["model"]
+    off, dep = kat["test_1_src_offset"], kat["test_1_src_depth"]
+    t = rt.TraceRays(m["vels"], m["depths"], 6, off, dep, 20, np.zeros(20), -1)
+    assert compare_times(t, kat["config1_ref_timeP"], TOL) == 0.0
+    t7 = rt.dff7(m["vels"], m["depths"], 6, off, dep, 20)["timeP"]
+    assert compare_times(t7, kat["config1_ref_timeP"], TOL) == 0.0
+    # librtmi_dff7.so: symbol `dff_` with seven arguments (subroutineR.f90:405)
+    lib7 = ctypes.CDLL(rt.raymod.LIB7_PATH)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    lib7.dff_.argtypes = [dp, dp, ip, dp, dp, ip, dp]
+    lib7.dff_.restype = None
+    v, d = np.array(m["vels"]), np.array(m["depths"])
+    o, z, out = np.array(off), np.array(dep), np.zeros(20)
+    nl, ns = ctypes.c_int(6), ctypes.c_int(20)
+    lib7.dff_(v.ctypes.data_as(dp), d.ctypes.data_as(dp), ctypes.byref(nl), o.ctypes.data_as(dp),
+              z.ctypes.data_as(dp), ctypes.byref(ns), out.ctypes.data_as(dp))
+    assert compare_times(out, kat["config1_ref_timeP"], TOL) == 0.0
+
+
+# ------------------------------------------------------------------------------------------
+# committed fixtures generated from the compiled reference
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_case_names())
+def test_reference_fixture(rt, name, golden_batches):
+    c = golden_batches[name]
+    t = rt.dff(c["vels"], c["depths"], c["depths"].size, c["off"], c["dep"], c["off"].size)["timeP"]
+    err = compare_times(t, c["timeP"], TOL)
+    assert err == 0.0, f"{name}: not bit-identical ({err:.3e} s)"
+
+
+# ------------------------------------------------------------------------------------------
+# seeded random inputs against the oracle
+# ------------------------------------------------------------------------------------------
+def test_random_models_vs_oracle(rt, O):
+    rng = np.random.default_rng(99)
+    for it in range(25):
+        k = int(rng.integers(2, 31))
+        d = np.sort(rng.uniform(100.1, 10000.1, k - 1))
+        v = rng.uniform(1500, 10000, k)
+        n = int(rng.integers(1, 5000))
+        off = rng.uniform(0, 12000, n)
+        dep = rng.uniform(1, 11000, n)
+        t = rt.dff(v, d, k - 1, off, dep, n)["timeP"]
+        assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_sizes(rt, O, n):
+    v, d, off, dep = c2_workload(max(n, 1), seed=5)
+    off, dep = off[:n], dep[:n]
+    t = rt.dff(v, d, 8, off, dep, n)["timeP"]
+    assert t.shape == (n,)
+    if n:
+        assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
+
+
+def test_bad_inputs_do_not_hang(rt, O):
+    """NaN / Inf source data: the reference loops forever (p0 never becomes 'good'); the HIP path and the
+    oracle report -999 for those sources and leave the others untouched."""
+    v, d, off, dep = c2_workload(512, seed=6)
+    off[3], dep[7], off[11], dep[13] = np.nan, np.nan, np.inf, np.inf
+    t = rt.dff(v, d, 8, off, dep, 512)["timeP"]
+    ref = O.oracle_dff(v, d, off, dep)
+    ok = np.ones(512, bool)
+    ok[[3, 7, 11, 13]] = False
+    assert compare_times(t[ok], ref[ok], TOL) == 0.0
+    assert np.array_equal(t[~ok], ref[~ok], equal_nan=True)  # -999 for NaN data; Inf offset follows the arithmetic
+
+
+def test_bad_arguments_raise(rt):
+    import torch
+    with pytest.raises(rt.RtmiError):
+        rt.dff([3000.0], [], 0, [1.0], [1.0], 1)
+    z = torch.zeros(4, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        rt.trace_device(z[:3], z[:3], z, z)  # vels must have NLayers+1 entries
+    with pytest.raises(ValueError):
+        rt.trace_device(z[:3].cpu(), z[:2], z, z)  # host tensor
+
+
+# ------------------------------------------------------------------------------------------
+# device-resident entry points
+# ------------------------------------------------------------------------------------------
+def test_trace_device_full_c2(rt, O):
+    """BASELINE config 2 at full size: 1e6 sources, 8 interfaces, single forward, fp64."""
+    import torch
+    n = 1_000_000
+    v, d, off, dep = c2_workload(n)
+    dv, dd = torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda")
+    do, dz = torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")
+    p = torch.empty(n, dtype=torch.float64, device="cuda")
+    t = rt.trace_device(dv, dd, do, dz, p_final=p)
+    torch.cuda.synchronize()
+    t = t.cpu().numpy()
+    ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
+    assert compare_times(t, ref, TOL) == 0.0
+    assert (ref == -999.0).sum() == 12  # the C2 stream has 12 non-converged sources
+    # final ray parameters: NaN for straight rays, identical elsewhere
+    p = p.cpu().numpy()
+    assert np.array_equal(np.isnan(p), nl == 1)
+    assert np.array_equal(p[nl > 1], pref[nl > 1])
+    # size-independent properties: order independence and determinism
+    perm = np.random.default_rng(0).permutation(n)
+    t2 = rt.trace_device(dv, dd, torch.tensor(off[perm], device="cuda"), torch.tensor(dep[perm], device="cuda"))
+    assert np.array_equal(t2.cpu().numpy(), t[perm])
+    t3 = rt.trace_device(dv, dd, do, dz)
+    assert np.array_equal(t3.cpu().numpy(), t)
+    # physics sanity on converged rays: slower than the straight line at the fastest velocity
+    okm = t != -999.0
+    assert np.all(t[okm] * v.max() >= np.hypot(off, dep)[okm] * (1 - 1e-12))
+
+
+def test_trace_batch_device_and_loglike(rt, O):
+    """Many models over shared sources (what LOGLHOOD_RT does per proposal), with the fused logL."""
+    import torch
+    rng = np.random.default_rng(31)
+    nm, n, ld = 37, 3001, 32
+    x, y = rng.uniform(10, 6500, n), rng.uniform(10, 4500, n)
+    off, dep = np.sqrt(x * x + y * y), rng.uniform(1050, 4200, n)
+    V = np.zeros((nm, ld))
+    D = np.zeros((nm, ld))
+    NL = np.zeros(nm, np.int32)
+    sd = rng.uniform(0.001, 0.07, nm)
+    for m in range(nm):
+        k = int(rng.integers(2, 31))
+        if m == 0:  # k = 1 as LOGLHOOD_RT calls it (loglhood.f90:137-144)
+            V[m, :2], D[m, 0], NL[m] = 4321.0, 9999.9, 1
+            continue
+        D[m, :k - 1] = np.sort(rng.uniform(100.1, 10000.1, k - 1))
+        V[m, :k] = rng.uniform(1500, 10000, k)
+        NL[m] = k - 1
+    true_t = O.oracle_dff(V[5, :NL[5] + 1], D[5, :NL[5]], off, dep)
+    obs = true_t + rng.normal(0, 0.016, n)
+    dev = "cuda"
+    tV, tD, tN = torch.tensor(V, device=dev), torch.tensor(D, device=dev), torch.tensor(NL, device=dev)
+    to, tz = torch.tensor(off, device=dev), torch.tensor(dep, device=dev)
+    tobs, tsd = torch.tensor(obs, device=dev), torch.tensor(sd, device=dev)
+    T, L = rt.trace_batch_device(tV, tD, tN, to, tz, obs=tobs, sd=tsd)
+    _, L2 = rt.trace_batch_device(tV, tD, tN, to, tz, obs=tobs, sd=tsd, want_timeP=False)
+    torch.cuda.synchronize()
+    T, L, L2 = T.cpu().numpy(), L.cpu().numpy(), L2.cpu().numpy()
+    assert np.array_equal(L, L2)
+    for m in range(nm):
+        ref = O.oracle_dff(V[m, :NL[m] + 1], D[m, :NL[m]], off, dep)
+        assert compare_times(T[m], ref, TOL) == 0.0
+        ll = O.oracle_loglhood_rt(obs, ref, sd[m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+
+
+def test_loglike_test_1_map(rt, kat):
+    """logL of the test_1 MAP model through the fused path = the reference's LOGLHOOD_RT value."""
+    import torch
+    m = kat["model"]
+    dev = "cuda"
+    V = torch.tensor([m["vels"] + [0.0]], device=dev, dtype=torch.float64)
+    D = torch.tensor([m["depths"] + [0.0, 0.0]], device=dev, dtype=torch.float64)
+    N = torch.tensor([6], device=dev, dtype=torch.int32)
+    g = kat["test_1_map_logL_survey"]
+    T, L = rt.trace_batch_device(V, D, N, torch.tensor(kat["test_1_src_offset"], device=dev),
+                                 torch.tensor(kat["test_1_src_depth"], device=dev),
+                                 obs=torch.tensor(kat["test_1_obs_RT"], device=dev),
+                                 sd=torch.tensor([g["sd"]], device=dev, dtype=torch.float64))
+    assert abs(float(L[0]) - g["value"]) < 1e-10 * abs(g["value"])
+    assert compare_times(T[0].cpu().numpy(), kat["config1_ref_timeP"], TOL) == 0.0
+
+
+def test_many_layers(rt, O):
+    """Up to the 1024-interface limit of the kernels (the reference's sampler copy stops at 99)."""
+    rng = np.random.default_rng(8)
+    for nl in (99, 100, 400, 1024):
+        d = np.cumsum(rng.uniform(5, 30, nl))
+        v = rng.uniform(1500, 8000, nl + 1)
+        off, dep = rng.uniform(10, 9000, 700), rng.uniform(1, d[-1] + 100, 700)
+        t = rt.dff(v, d, nl, off, dep, 700)["timeP"]
+        assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
+    with pytest.raises(rt.RtmiError):
+        rt.dff(np.ones(1026) * 3000, np.arange(1, 1026.0), 1025, [1.0], [1.0], 1)
