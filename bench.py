@@ -54,6 +54,31 @@ def c2_workload(n: int, seed: int = 12345, shard: int = 0):
     return v, d, off, dep
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if one is set
+    (a 1-GPU box exposes all host CPUs in the mask but grants a 16-CPU share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+            break
+        except Exception:
+            continue
+    return min(n, int(os.environ.get("RTMI_BENCH_MAX_THREADS", "64")))
+
+
 def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
     """Time the CPU restatement on this host: all cores (threads over source slices; the C code
     holds no shared state and ctypes releases the GIL) and one core.  Bounded to ~budget_s."""
@@ -61,11 +86,7 @@ def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
     from oracle import oracle as O
 
     n = off.size
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     O.oracle_dff(v, d, off[:1000], dep[:1000])  # load + warm
     # single thread, on a sample sized to ~3 s
     n1 = min(n, 1_000_000)

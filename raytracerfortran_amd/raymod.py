@@ -64,6 +64,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the
+    # system one, libamdhip64.so.7) and pull it in by file name; if librtmi.so were loaded first it would
+    # bind the system runtime and torch would then bring a SECOND runtime into the process, which cannot
+    # see the GPU ("No HIP GPUs are available").  Importing torch first makes the loader satisfy
+    # librtmi.so's DT_NEEDED libamdhip64.so.7 with the runtime torch already loaded, so device pointers
+    # and streams are shared.  Without torch the system runtime (/opt/rocm) is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise RtmiError(f"{p} not found: build it with `python -m raytracerfortran_amd.build` "
                         "(hipcc, gfx950).  There is no CPU fallback.")

@@ -1,0 +1,26 @@
+"""The Fortran caller path on the GPU box: shim/test_shim (amdflang-built in the build container, travels with
+the snapshot) does `USE RAYMOD; CALL TraceRays(...)` like LOGLHOOD_RT (loglhood.f90:135) against shim/raymod.f90,
+which forwards to librtmi.so through ISO_C_BINDING."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, compare_times
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fortran_tracerays_caller(kat):
+    exe = os.path.join(ROOT, "shim", "test_shim")
+    if not os.path.exists(exe):
+        pytest.skip("shim/test_shim not built (needs amdflang: make -C shim)")
+    m = kat["model"]
+    off, dep = kat["test_1_src_offset"], kat["test_1_src_depth"]
+    lines = [f"{len(m['depths'])} {len(off)}", " ".join(repr(x) for x in m["vels"]),
+             " ".join(repr(x) for x in m["depths"])] + [f"{o!r} {z!r}" for o, z in zip(off, dep)]
+    p = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    t = np.array([float(x) for x in p.stdout.split()])
+    assert compare_times(t, kat["config1_ref_timeP"], 1e-9) == 0.0
