@@ -96,10 +96,18 @@ int rtmi_device_cus(void);
  * sources of one model.  d_p_final may be NULL; when given it receives the final
  * ray parameter of each source (NaN for straight top-layer rays), from which the
  * rays.dat records are rebuilt on the host.
+ * d_work / work_bytes: optional device scratch of >= rtmi_trace_work_bytes(nsrc,
+ * nlayers) bytes.  With it, large source sets (nsrc >= RTMI_BINNED_MIN_NSRC) take
+ * the binned pipeline (sources regrouped by layer, lanes refilled as they finish:
+ * ~3x the throughput of the single launch); without it (NULL / too small) the
+ * single-launch kernel runs.  Results are bit-identical either way.
  */
+#define RTMI_BINNED_MIN_NSRC 32768
 int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
                       const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
-                      double *d_timeP, double *d_p_final, void *stream);
+                      double *d_timeP, double *d_p_final, void *d_work, int64_t work_bytes,
+                      void *stream);
+int64_t rtmi_trace_work_bytes(int64_t nsrc, int nlayers);
 
 /*
  * Many models over one shared source set: what nmodels consecutive calls of

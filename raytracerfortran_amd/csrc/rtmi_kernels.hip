@@ -6,308 +6,70 @@
 //                  ray parameter p by the guarded Newton / bisection
 //                  hybrid on f(p) = R - sum H_i V_i p / sqrt(1-p^2 V_i^2)   (:77-153, :226-405)
 //                  t = sum H_i / (V_i sqrt(1 - p^2 V_i^2)), or -999    (:156-169)
-// The reference stops its root-find at |f| < 0.1 m, so t depends on the exact
-// iteration sequence: the kernel reproduces the reference's arithmetic operation
-// for operation in IEEE fp64.  THIS FILE MUST BE COMPILED WITH -ffp-contract=off
-// (build.py does); hipcc's default contraction would fuse 1 - (x*x)*(V*V) and break parity.
+// The reference stops its root-find at |f| < 0.1 m, so t depends on the exact iteration
+// sequence: the kernels reproduce the reference's arithmetic operation for operation in IEEE
+// fp64 (rtmi_device.hpp).  THIS FILE MUST BE COMPILED WITH -ffp-contract=off (build.py does).
 //
-// Mapping to the machine (DESIGN.md has the numbers):
-//   * one lane per source; 64-lane waves; 256-thread workgroups, grid-stride over source tiles;
-//   * the model is tiny (<= 2*nlayers+1 doubles) and shared by every lane, so each
-//     workgroup derives the layer table once -- thickness H, H*V, V*V, running sum of
-//     H/V, running max of V -- into LDS in exactly the reference's rounding order;
-//     the per-layer loop reads it with wave-uniform addresses (LDS broadcast), the
-//     per-lane entries (layer of the source) with a gather;
-//   * the expensive primitive is "evaluate f and f' at x" (one sqrt and two divides
-//     per layer).  The three solver branches of GetPTime are folded into one per-lane
-//     state machine around a single converged evaluation loop, so a wave never
-//     executes the layer loop for one branch while the lanes of another idle;
-//     f and f' share their sqrt, and solvebst's duplicate costFunc call (:370,:378)
-//     is evaluated once -- same values, fewer instructions;
-//   * src_offset / src_depth are read once, coalesced (8 B/lane), timeP written once:
-//     24 algorithmic bytes per travel time.  The kernel is fp64-VALU bound.
+// Two paths (DESIGN.md has the measurements):
+//
+//  (1) trace_kernel -- one launch, one lane per source in input order.  The three solver branches
+//      of GetPTime are folded into one per-lane state machine around a single wave-converged
+//      "evaluate f and f' at x" loop (one sqrt + two divides per layer; f and f' share the sqrt,
+//      solvebst's duplicate costFunc call is evaluated once).  Used for small NSrc and for the
+//      many-models batch.  Its cost is set by the slowest lane of each wave: deepest source x most
+//      evaluations.
+//
+//  (2) the binned pipeline for large NSrc -- same arithmetic per source, scheduled so that lanes
+//      stay busy:
+//        bin_count_kernel    nl per source + histogram of nl
+//        bin_scatter_kernel  counting sort by DESCENDING nl (so a wave's layer loop has one trip
+//                            count), p0 per source, straight top-layer rays finished here
+//        solve_kernel        persistent waves; a lane that finishes its source immediately takes
+//                            the next one of its wave's queue (lane refill), so the evaluation loop
+//                            runs with nearly all 64 lanes active instead of waiting for the
+//                            slowest source
+//        time_kernel         t from the final ray parameter, in input order (coalesced)
+//      HBM traffic rises from 24 to ~150 B per source, still a few percent of the HBM roof; the
+//      kernel is fp64-VALU bound and this trade buys ~3x lane utilisation.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rtmi_device.hpp"
 #include "rtmi_kernels.h"
 
 namespace rtmi {
 
-// Per-lane solver states.  One evaluation of (f, f') separates two transitions.
-enum : int {
-    ST_INIT = 0,    // evaluated at p0: choose the branch                       (:136-153)
-    ST_BIS0 = 1,    // evaluated at x1 = 1e-10: orient the bisection            (:354-365)
-    ST_BIS = 2,     // evaluated at xmid: one bisection trip                    (:367-397)
-    ST_NEWTON = 3,  // evaluated at x: one Newton iteration                     (:269-311)
-    ST_FINAL = 4,   // evaluated at x after 15 updates: the inverted conv test  (:314-330)
-    ST_DONE = 5
-};
+// =============================================================================================
+// (1) single-launch path
+// =============================================================================================
 
-// LDS layout: 8 arrays of (nlayers + 1) doubles.
-struct LayerTable {
-    double *D;     // D[i]    depth to interface i                       i < nlayers
-    double *V;     // V[i]    velocity of layer i                        i <= nlayers
-    double *H;     // H[i]    thickness of a fully crossed layer i       i < nlayers
-    double *HV;    // HV[i]   H[i]*V[i]                                  i < nlayers
-    double *VV;    // VV[i]   V[i]*V[i]                                  i <= nlayers
-    double *PS;    // PS[i]   ((H0/V0 + H1/V1) + ...) + Hi/Vi            i < nlayers
-    double *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
-    double *Q;     // scratch H[i]/V[i]
-};
-
-__device__ __forceinline__ LayerTable carve_table(double *lds, int nlayers)
-{
-    const int n1 = nlayers + 1;
-    LayerTable t;
-    t.D = lds;
-    t.V = lds + n1;
-    t.H = lds + 2 * n1;
-    t.HV = lds + 3 * n1;
-    t.VV = lds + 4 * n1;
-    t.PS = lds + 5 * n1;
-    t.VMAX = lds + 6 * n1;
-    t.Q = lds + 7 * n1;
-    return t;
-}
-
-// Derive the table of one model.  The roundings are the reference's:
-//   H(i) = depths(i) - depths(i-1)            InsertLayer :67
-//   (H*V) and (V*V) as separate products      costFunc :195, costFunc_Prime :214-219
-//   sum(depths/vp) left to right              GetPTime :112
-__device__ __forceinline__ void stage_model(const LayerTable &t, const double *__restrict__ vels,
-                                            const double *__restrict__ depths, int nlayers)
-{
-    for (int i = threadIdx.x; i <= nlayers; i += blockDim.x) {
-        const double v = vels[i];
-        t.V[i] = v;
-        t.VV[i] = v * v;
-        if (i < nlayers) {
-            const double d = depths[i];
-            const double h = (i == 0) ? d : d - depths[i - 1];
-            t.D[i] = d;
-            t.H[i] = h;
-            t.HV[i] = h * v;
-            t.Q[i] = h / v;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = t.Q[0];
-        double m = t.V[0];
-        t.PS[0] = s;
-        t.VMAX[0] = m;
-        for (int i = 1; i <= nlayers; ++i) {
-            const double v = t.V[i];
-            m = (v > m) ? v : m;  // maxval(): order-free
-            t.VMAX[i] = m;
-            if (i < nlayers) {
-                s = s + t.Q[i];
-                t.PS[i] = s;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
-// `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
-// `nfull_wave` = max of nfull over the wave keeps the loop wave-uniform.
-__device__ __forceinline__ void eval_f_fp(const LayerTable &t, double x, int nfull, int nfull_wave,
-                                          double hvl, double vvl, double R, double &f, double &fp)
-{
-    const double xx = x * x;
-    double sf = 0.0, sp = 0.0;
-    for (int i = 0; i < nfull_wave; ++i) {
-        const double hv = t.HV[i];
-        const double vv = t.VV[i];
-        const double s = sqrt(1.0 - xx * vv);
-        const double tf = (hv * x) / s;
-        const double tp = hv / ((s * s) * s);
-        if (i < nfull) {
-            sf = sf + tf;
-            sp = sp + tp;
-        }
-    }
-    {
-        const double s = sqrt(1.0 - xx * vvl);
-        sf = sf + (hvl * x) / s;
-        sp = sp + hvl / ((s * s) * s);
-    }
-    f = R - sf;
-    fp = -sp;
-}
-
-// One source.  Returns the travel time; *p_out gets the final ray parameter.
-// All lanes of the wave must call this together (wave-uniform loops inside);
+// One source per lane, all lanes of the wave together (wave-uniform loops inside);
 // `valid` = false lanes carry a dummy source and their result is discarded.
-__device__ __forceinline__ double trace_one(const LayerTable &t, int nlayers, double R, double z,
-                                            bool valid, double &p_out)
+__device__ __forceinline__ double trace_one(const LayerTable &t, int nlayers, double R, double z, bool valid,
+                                            double &p_out)
 {
-    // ---- whichLayer (:9-32): first interface strictly below the source -------------------
-    int nl = 0;  // 1-based, 0 = not found yet
-    for (int i = 0; i < nlayers; ++i) {
-        const bool below = t.D[i] > z;  // == (depths(i) - dph > 0)
-        if (below && nl == 0)
-            nl = i + 1;
-        if (__all(nl != 0))
-            break;
-    }
-    if (nl == 0)
-        nl = (t.D[nlayers - 1] - z < 0.0) ? nlayers + 1 : nlayers;
-
+    const int nl = which_layer(t, nlayers, z);
     const bool straight = (nl == 1);  // source in the top layer (:94-97)
     const bool active = valid && !straight;
+    const int il = active ? nl - 1 : 1;  // 0-based layer of the source; dummy lanes use layer 1
+    Lane s;
+    lane_setup(s, t, il, R, z);
+    const double p0 = active ? initial_p0(t, il, R, z) : 0.0;
+    lane_start(s, p0);
+    if (!active || p0 != p0)
+        s.st = ST_DONE;
+    const int nfull_wave = wave_max_i32(active ? s.nfull : 0);
 
-    // ---- InsertLayer (:38-69) as table lookups -------------------------------------------
-    const int il = active ? nl - 1 : 1;  // 0-based index of the source's layer; dummy lanes use 1
-    const int ilc = il > nlayers ? nlayers : il;
-    const int nfull = ilc;               // layers fully crossed
-    const double vl = t.V[ilc];
-    const double hl = z - t.D[ilc - 1];  // depths_new(nl) - depths_new(nl-1)
-    const double hvl = hl * vl;
-    const double vvl = t.VV[ilc];
-    const double vmax = t.VMAX[ilc];
-    const int nfull_wave = wave_max_i32(active ? nfull : 0);
-
-    // ---- GetPTime head (:112-133) -----------------------------------------------------------
-    const double c_harmonic = z / (t.PS[ilc - 1] + hl / vl);
-    const double cos_t = z / sqrt(R * R + z * z);
-    double p0 = cos_t / c_harmonic;
-    const double vm1sq = (vmax + 1.0) * (vmax + 1.0);
-    // sum(sqrt(1-(p0**2)*(vp+1)**2)) is NaN  <=>  (p0*p0)*(vmax+1)^2 > 1  (monotone in V; the
-    // subtraction from 1 has the exact sign).  The reference loops forever for NaN/Inf p0
-    // (NaN source data); here such a lane gives up and reports -999.
-    bool hopeless = false;
-    {
-        int guard = 0;
-        while (active && !hopeless && !((p0 * p0) * vm1sq <= 1.0)) {
-            p0 = p0 / 2.0;
-            if (++guard > 2200 || p0 != p0)
-                hopeless = true;
-        }
-    }
-
-    const double vmi = 1.0 / vmax;         // 1/maxval(vp)
-    const double safe = vmi - 1e-10;       // 1/maxval(V)-(1d-10)      (:142, :388)
-
-    int st = (active && !hopeless) ? ST_INIT : ST_DONE;
-    double xe = p0;   // where the next evaluation happens
-    double x = p0;    // Newton iterate
-    double xb = 0.0;  // bisection bracket end `x` of solvebst
-    double dx = 0.0;
-    int k = 0;        // trip counter of the current loop
-    bool conv = false;
-
-    while (__any(st != ST_DONE)) {
+    while (__any(s.st != ST_DONE)) {
         double f, fp;
-        eval_f_fp(t, xe, nfull, nfull_wave, hvl, vvl, R, f, fp);
-
-        // Exactly one transition per lane and evaluation; no early `continue`, so the
-        // wave reconverges at the bottom of the loop before the next __any().
-        bool newton_step = (st == ST_NEWTON);
-        if (st == ST_INIT) {
-            const double check_x = xe - f / fp;
-            if (f < 0.0 || check_x < safe) {
-                st = ST_NEWTON;  // solve(p0): its first costFunc/costFunc_Prime pair is this one
-                k = 1;
-                x = xe;
-                newton_step = true;
-            } else {
-                st = ST_BIS0;  // solvebst(1d-10, 1/maxval(vp)-1d-12)
-                xe = 1e-10;
-            }
-        } else if (st == ST_BIS0) {
-            const double x1 = 1e-10, x2 = vmi - 1e-12;
-            if (f < 0.0) {
-                xb = x1;
-                dx = x2 - x1;
-            } else {
-                xb = x2;
-                dx = x1 - x2;
-            }
-            k = 1;
-            dx = dx * 0.5;
-            xe = xb + dx;
-            st = ST_BIS;
-        } else if (st == ST_BIS) {
-            // xe is xmid, f is fmid (== fx), fp is fxprime
-            bool done = false;
-            if (f < 0.0)
-                xb = xe;
-            if (f == 0.0) {
-                done = true;
-            } else {
-                const double check_x = xb - f / fp;
-                if (check_x < safe) {
-                    xb = xe;
-                    done = true;
-                } else if (fabs(f) < 0.1) {
-                    done = true;
-                }
-            }
-            if (!done) {
-                if (k == 20) {
-                    done = true;
-                } else {
-                    ++k;
-                    dx = dx * 0.5;
-                    xe = xb + dx;
-                }
-            }
-            if (done) {
-                st = ST_NEWTON;  // p0 = p_final; call solve(p0, ...)   (:151-152)
-                k = 1;
-                x = xb;
-                xe = xb;
-            }
-        } else if (st == ST_FINAL) {
-            conv = fabs(f) > 0.1;  // the reference's inverted test (:327-330)
-            st = ST_DONE;
-        }
-
-        if (newton_step) {
-            if (fabs(f) < 0.1) {
-                conv = true;
-                st = ST_DONE;
-            } else {
-                x = x - f / fp;
-                if (x > vmi)
-                    x = vmi - 1e-9;
-                xe = x;
-                if (k == 15)
-                    st = ST_FINAL;
-                else
-                    ++k;
-            }
-        }
+        eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
+        lane_advance(s, f, fp);
     }
 
-    // ---- travel time (:156, :165-169) ---------------------------------------------------------
-    const double pp = x * x;
-    double tt = 0.0;
-    for (int i = 0; i < nfull_wave; ++i) {
-        const double cosv = sqrt(1.0 - pp * t.VV[i]);
-        const double ti = t.H[i] / (t.V[i] * cosv);
-        if (i < nfull)
-            tt = tt + ti;
-    }
-    {
-        const double cosv = sqrt(1.0 - pp * vvl);
-        tt = tt + hl / (vl * cosv);
-    }
-    if (!conv)
+    double tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z);
+    if (!s.conv)
         tt = -999.0;
-    p_out = x;
+    p_out = s.x;
     if (straight) {
         tt = sqrt(z * z + R * R) / t.V[0];
         p_out = __builtin_nan("");
@@ -381,6 +143,204 @@ __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, c
     logL[m] = -(n / 2.0) * log(2.0 * PI2) - (s / (2.0 * (sdm * sdm)) + n * log(sdm));
 }
 
+// =============================================================================================
+// (2) binned pipeline
+// =============================================================================================
+
+// Bin b = nl (1 .. nlayers+1).  hist/cursor have nlayers+2 entries, zeroed before the launch.
+__global__ __launch_bounds__(RTMI_BLOCK) void bin_count_kernel(BinArgs a)
+{
+    extern __shared__ double lds[];
+    const LayerTable t = carve_table(lds, a.nlayers);
+    uint32_t *lh = reinterpret_cast<uint32_t *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1));
+    const int nb = a.nlayers + 2;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        lh[i] = 0;
+    stage_model(t, a.d_vels, a.d_depths, a.nlayers);  // ends with a barrier
+
+    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
+        const bool valid = k < a.nsrc;
+        const double z = valid ? a.d_src_depth[k] : 0.0;
+        const int nl = which_layer(t, a.nlayers, z);
+        if (valid) {
+            a.key[k] = nl;
+            atomicAdd(&lh[nl], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        if (lh[i])
+            atomicAdd(&a.hist[i], lh[i]);
+}
+
+// Counting sort by descending nl + per-source start values.  One tile of RTMI_BLOCK sources per
+// workgroup iteration; positions inside a bin are handed out by atomics (any order is fine: every
+// source's arithmetic is independent of where it is processed).
+__global__ __launch_bounds__(RTMI_BLOCK) void bin_scatter_kernel(BinArgs a)
+{
+    extern __shared__ double lds[];
+    const LayerTable t = carve_table(lds, a.nlayers);
+    const int nb = a.nlayers + 2;
+    uint32_t *base = reinterpret_cast<uint32_t *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1));  // bin start
+    uint32_t *lc = base + nb;                                                                   // tile count
+    uint32_t *gb = lc + nb;                                                                     // tile start
+    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;  // descending nl: deepest bin first, straight rays (nl == 1) last
+        for (int b = nb - 1; b >= 0; --b) {
+            base[b] = acc;
+            acc += a.hist[b];
+        }
+    }
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        lc[i] = 0;
+    __syncthreads();
+
+    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
+        const bool valid = k < a.nsrc;
+        int nl = 1;
+        uint32_t rank = 0;
+        double R = 1.0, z = 1.0;
+        if (valid) {
+            nl = a.key[k];
+            R = a.d_src_offset[k];
+            z = a.d_src_depth[k];
+            rank = atomicAdd(&lc[nl], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+            const uint32_t c = lc[i];
+            if (c)
+                gb[i] = base[i] + atomicAdd(&a.cursor[i], c);
+        }
+        __syncthreads();
+        if (valid) {
+            if (nl == 1) {
+                // straight ray in the top layer (:94-97): finished here
+                a.d_timeP[k] = sqrt(z * z + R * R) / t.V[0];
+                if (a.d_pfin)
+                    a.d_pfin[k] = __builtin_nan("");
+            } else {
+                const int il = nl - 1;
+                const double p0 = initial_p0(t, il, R, z);
+                const uint32_t pos = gb[nl] + rank;
+                a.bR[pos] = R;
+                a.bz[pos] = z;
+                a.bp0[pos] = p0;
+                a.bidx[pos] = (uint32_t)k;
+                a.bnl[pos] = nl;
+                if (p0 != p0) {
+                    // the reference never returns for this source (NaN/Inf data); report -999
+                    a.d_timeP[k] = -999.0;
+                    if (a.d_pfin)
+                        a.d_pfin[k] = p0;
+                    a.key[k] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += blockDim.x)
+            lc[i] = 0;
+        __syncthreads();
+    }
+}
+
+// Persistent waves with lane refill.  Wave w owns chunks w, w + nwaves, w + 2 nwaves, ... of 64
+// consecutive sources in binned order (interleaving gives every wave the same mix of bins); a lane
+// whose source is finished takes the next entry of that queue once `refill_min` lanes are idle.
+__global__ __launch_bounds__(RTMI_BLOCK) void solve_kernel(BinArgs a)
+{
+    extern __shared__ double lds[];
+    const LayerTable t = carve_table(lds, a.nlayers);
+    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
+
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (RTMI_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (RTMI_BLOCK / 64);
+    const int64_t n_solve = a.nsrc - (int64_t)a.hist[1];  // everything but the straight rays
+    const int64_t nchunks = (n_solve + 63) / 64;
+    const int qend = (int)((nchunks + nwaves - 1) / nwaves) * 64;  // queue length of every wave
+    int qnext = 0;
+
+    Lane s;
+    s.st = ST_DONE;
+    s.nfull = 0;
+    s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = 0.0;
+    s.k = 0;
+    s.conv = false;
+    uint32_t orig = 0;
+    int nl = 0;
+    int nfull_wave = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(s.st == ST_DONE);
+        const int nidle = __popcll(idle);
+        if (qnext < qend && nidle >= a.refill_min) {
+            if (s.st == ST_DONE) {
+                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const int q = qnext + rank;
+                if (q < qend) {
+                    const int64_t pos = (wave + (int64_t)(q >> 6) * nwaves) * 64 + (q & 63);
+                    if (pos < n_solve) {
+                        const double p0 = a.bp0[pos];
+                        if (p0 == p0) {  // NaN: already reported by bin_scatter_kernel
+                            nl = a.bnl[pos];
+                            orig = a.bidx[pos];
+                            lane_setup(s, t, nl - 1, a.bR[pos], a.bz[pos]);
+                            lane_start(s, p0);
+                        }
+                    }
+                }
+            }
+            qnext += nidle;
+            nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
+        }
+        if (__all(s.st == ST_DONE)) {
+            if (qnext >= qend)
+                break;
+            continue;  // nidle == 64 >= refill_min: the next trip refills
+        }
+
+        double f, fp;
+        eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
+        const bool was_busy = (s.st != ST_DONE);
+        lane_advance(s, f, fp);
+        if (was_busy && s.st == ST_DONE) {
+            a.d_pfin[orig] = s.x;
+            a.key[orig] = nl | (s.conv ? RTMI_KEY_CONV : 0);
+        }
+    }
+}
+
+// t = sum H_i / (V_i sqrt(1 - p^2 V_i^2)) for every traced source, input order.
+__global__ __launch_bounds__(RTMI_BLOCK) void time_kernel(BinArgs a)
+{
+    extern __shared__ double lds[];
+    const LayerTable t = carve_table(lds, a.nlayers);
+    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
+    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
+        const bool valid = k < a.nsrc;
+        const int kv = valid ? a.key[k] : 0;
+        const int nl = kv & RTMI_KEY_NL_MASK;
+        const bool traced = nl > 1;  // 1: straight ray, 0: reported by bin_scatter_kernel
+        const int il = traced ? nl - 1 : 1;
+        const double z = traced ? a.d_src_depth[k] : 1.0;
+        const double p = traced ? a.d_pfin[k] : 0.0;
+        const int nfull_wave = wave_max_i32(traced ? il : 0);
+        double tt = travel_time(t, p, il, nfull_wave, il, z);
+        if (!(kv & RTMI_KEY_CONV))
+            tt = -999.0;
+        if (traced)
+            a.d_timeP[k] = tt;
+    }
+}
+
 }  // namespace rtmi
 
 // ---------------------------------------------------------------------------------------------
@@ -407,7 +367,7 @@ extern "C" hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels
 {
     using namespace rtmi;
     const TraceArgs a = *args;
-    const size_t lds_bytes = (size_t)8 * (max_nlayers + 1) * sizeof(double);
+    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(double);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
@@ -430,5 +390,69 @@ extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, c
     const int grid = (nmodels + block - 1) / block;
     hipLaunchKernelGGL(rtmi::loglike_kernel, dim3(grid), dim3(block), 0, stream, d_partial, nparts, d_sd, ndat,
                        nmodels, d_logL);
+    return hipGetLastError();
+}
+
+extern "C" size_t rtmi_binned_work_bytes(int64_t nsrc, int nlayers)
+{
+    // hist | cursor (u32 each, nlayers+2, padded) | key i32 | bidx u32 | bnl i32 | bR bz bp0 pfin f64
+    const size_t nb = ((size_t)nlayers + 2 + 63) / 64 * 64;
+    const size_t n = ((size_t)nsrc + 63) / 64 * 64;
+    return 2 * nb * sizeof(uint32_t) + n * (3 * sizeof(uint32_t) + 4 * sizeof(double));
+}
+
+extern "C" hipError_t rtmi_launch_binned(const double *d_vels, const double *d_depths, int nlayers,
+                                         const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                                         double *d_timeP, double *d_p_final, void *d_work, int num_cus,
+                                         int waves_per_simd, int refill_min, hipStream_t stream)
+{
+    using namespace rtmi;
+    const size_t nb = ((size_t)nlayers + 2 + 63) / 64 * 64;
+    const size_t n = ((size_t)nsrc + 63) / 64 * 64;
+    char *w = static_cast<char *>(d_work);
+    BinArgs a;
+    a.d_vels = d_vels;
+    a.d_depths = d_depths;
+    a.nlayers = nlayers;
+    a.refill_min = refill_min < 1 ? 1 : (refill_min > 64 ? 64 : refill_min);
+    a.d_src_offset = d_src_offset;
+    a.d_src_depth = d_src_depth;
+    a.nsrc = nsrc;
+    a.d_timeP = d_timeP;
+    a.hist = reinterpret_cast<uint32_t *>(w);
+    a.cursor = a.hist + nb;
+    w += 2 * nb * sizeof(uint32_t);
+    a.bR = reinterpret_cast<double *>(w);
+    a.bz = a.bR + n;
+    a.bp0 = a.bz + n;
+    double *pfin_ws = a.bp0 + n;
+    w += 4 * n * sizeof(double);
+    a.key = reinterpret_cast<int32_t *>(w);
+    a.bidx = reinterpret_cast<uint32_t *>(w) + n;
+    a.bnl = reinterpret_cast<int32_t *>(w) + 2 * n;
+    a.d_pfin = d_p_final ? d_p_final : pfin_ws;
+
+    hipError_t e = hipMemsetAsync(a.hist, 0, 2 * nb * sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
+    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (nlayers + 1) * sizeof(double);
+    const size_t bins = (size_t)3 * (nlayers + 2) * sizeof(uint32_t);
+    const int64_t ntiles = (nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
+    int64_t gtiles = (int64_t)num_cus * 8;
+    if (gtiles > ntiles)
+        gtiles = ntiles;
+    const dim3 block(RTMI_BLOCK, 1, 1);
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)gtiles), block, table + bins, stream, a);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)gtiles), block, table + bins, stream, a);
+    // solve: waves_per_simd persistent waves on each of the 4 SIMDs of every CU, never more waves
+    // than chunks
+    const int64_t nchunks = (nsrc + 63) / 64;
+    int64_t gsolve = (int64_t)num_cus * waves_per_simd;  // workgroups of 4 waves
+    if (gsolve * (RTMI_BLOCK / 64) > nchunks)
+        gsolve = (nchunks + RTMI_BLOCK / 64 - 1) / (RTMI_BLOCK / 64);
+    if (gsolve < 1)
+        gsolve = 1;
+    hipLaunchKernelGGL(solve_kernel, dim3((unsigned)gsolve), block, table, stream, a);
+    hipLaunchKernelGGL(time_kernel, dim3((unsigned)gtiles), block, table, stream, a);
     return hipGetLastError();
 }

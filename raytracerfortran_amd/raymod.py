@@ -44,7 +44,9 @@ SIGNATURES = {
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
     "rtmi_device_cus": (ctypes.c_int, []),
-    "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
+                                         ctypes.c_int64, _vp]),
+    "rtmi_trace_work_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     "rtmi_trace_batch_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64,
                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
@@ -196,9 +198,17 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(s.cuda_stream)
 
 
-def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, stream=None):
+def trace_work(nsrc: int, nlayers: int, device):
+    """Scratch tensor for trace_device's binned pipeline (rtmi_trace_work_bytes); reuse it across calls."""
+    import torch
+    nbytes = int(load_library().rtmi_trace_work_bytes(int(nsrc), int(nlayers)))
+    return torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=device)
+
+
+def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, work=None, stream=None):
     """One forward evaluation on resident data (rtmi_trace_device).  Asynchronous on `stream`
-    (default: torch's current stream).  Returns timeP."""
+    (default: torch's current stream).  `work` (from trace_work) enables the binned pipeline for
+    large source sets; results are identical with and without it.  Returns timeP."""
     import torch
     lib = load_library()
     nlayers = int(depths.numel())
@@ -214,7 +224,9 @@ def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, 
     f64 = torch.float64
     _check(lib.rtmi_trace_device(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers,
                                  _ptr(src_offset, f64, "src_offset"), _ptr(src_depth, f64, "src_depth"), n,
-                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"), _stream_ptr(stream)))
+                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"),
+                                 _ptr(work, f64, "work"), int(work.numel() * 8) if work is not None else 0,
+                                 _stream_ptr(stream)))
     return timeP
 
 
