@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--nsrc", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
-    ap.add_argument("--path", choices=["auto", "single", "binned"], default="auto",
+    ap.add_argument("--path", choices=["auto", "plain", "fused"], default="auto",
                     help="kernel path of rtmi_trace_device (A/B runs; auto = what the library picks)")
     args = ap.parse_args()
     if args.path != "auto":
@@ -202,11 +202,10 @@ def main():
     dv, dd = torch.tensor(v, device=dev), torch.tensor(d, device=dev)
     do, dz = torch.tensor(off, device=dev), torch.tensor(dep, device=dev)
     dt = torch.empty(n, dtype=torch.float64, device=dev)
-    work = rt.trace_work(n, d.size, dev)  # scratch of the binned pipeline, allocated once
     stream = torch.cuda.current_stream()
 
     def step():
-        rt.trace_device(dv, dd, do, dz, timeP=dt, work=work, stream=stream)
+        rt.trace_device(dv, dd, do, dz, timeP=dt, stream=stream)
 
     elapsed, kern_ms = timed_steps(step, args.steps, args.warmup, world, dist if world > 1 else None, dev,
                                    sync=torch.cuda.synchronize,
@@ -234,7 +233,7 @@ def main():
                        "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rtmi::trace_kernel<false,true,false>", "kernel_ms": kern_ms,
+                         "kernel": "rtmi::fused_kernel<false>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
                          "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; "
                                  "see DESIGN.md"},

@@ -83,6 +83,14 @@ const char *rtmi_last_error(void);
 int rtmi_version(void);
 /* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
 int rtmi_device_cus(void);
+/*
+ * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
+ *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel
+ *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 3)
+ *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
+ * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN.
+ */
+int rtmi_set_option(const char *name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Device-resident entry points: every pointer is a DEVICE pointer, `stream`
@@ -96,18 +104,14 @@ int rtmi_device_cus(void);
  * sources of one model.  d_p_final may be NULL; when given it receives the final
  * ray parameter of each source (NaN for straight top-layer rays), from which the
  * rays.dat records are rebuilt on the host.
- * d_work / work_bytes: optional device scratch of >= rtmi_trace_work_bytes(nsrc,
- * nlayers) bytes.  With it, large source sets (nsrc >= RTMI_BINNED_MIN_NSRC) take
- * the binned pipeline (sources regrouped by layer, lanes refilled as they finish:
- * ~3x the throughput of the single launch); without it (NULL / too small) the
- * single-launch kernel runs.  Results are bit-identical either way.
+ * Source sets of RTMI_FUSED_MIN_NSRC or more take the fused large-N kernel (each wave sorts its
+ * sources by layer in LDS and refills lanes as they finish), smaller ones the plain one-lane-per-
+ * source kernel.  Results are bit-identical either way.
  */
-#define RTMI_BINNED_MIN_NSRC 32768
+#define RTMI_FUSED_MIN_NSRC 8192
 int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
                       const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
-                      double *d_timeP, double *d_p_final, void *d_work, int64_t work_bytes,
-                      void *stream);
-int64_t rtmi_trace_work_bytes(int64_t nsrc, int nlayers);
+                      double *d_timeP, double *d_p_final, void *stream);
 
 /*
  * Many models over one shared source set: what nmodels consecutive calls of

@@ -53,25 +53,23 @@ struct Context {
     size_t model_cap = 0;
     double *d_src = nullptr;    // offset | depth | timeP | p_final
     size_t src_cap = 0;
-    double *d_work = nullptr;   // scratch of the binned pipeline
-    size_t work_cap = 0;        // in doubles
 };
 
-// Tuning knobs of the binned pipeline, overridable from the environment for A/B runs.
+// Tuning knobs of the fused kernel, overridable from the environment for A/B runs.
 struct Tuning {
-    int force_path;      // 0 auto, 1 single launch, 2 binned
-    int solve_waves;     // persistent waves per SIMD in solve_kernel
+    int force_path;      // 0 auto, 1 plain kernel, 2 fused kernel
+    int solve_waves;     // resident waves per SIMD of the fused kernel
     int refill_min;      // idle lanes that trigger a refill
 };
 
-const Tuning &tuning()
+Tuning &tuning()
 {
-    static const Tuning t = [] {
+    static Tuning t = [] {
         Tuning v{0, 3, 16};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
-            if (!strcmp(e, "single"))
+            if (!strcmp(e, "plain"))
                 v.force_path = 1;
-            else if (!strcmp(e, "binned"))
+            else if (!strcmp(e, "fused"))
                 v.force_path = 2;
         }
         if (const char *e = getenv("RTMI_SOLVE_WAVES"))
@@ -170,20 +168,13 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
     rc = grow(&c.d_src, &c.src_cap, 4 * n);
     if (rc)
         return rc;
-    const int64_t wbytes = rtmi_trace_work_bytes(nsrc, nlayers);
-    if (nsrc >= RTMI_BINNED_MIN_NSRC || tuning().force_path == 2) {
-        rc = grow(&c.d_work, &c.work_cap, (size_t)(wbytes + 7) / 8);
-        if (rc)
-            return rc;
-    }
     double *d_vels = c.d_model, *d_depths = c.d_model + nlayers + 1;
     double *d_off = c.d_src, *d_dep = c.d_src + n, *d_t = c.d_src + 2 * n, *d_p = c.d_src + 3 * n;
     HIP_TRY(hipMemcpyAsync(d_vels, vels, (size_t)(nlayers + 1) * sizeof(double), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipMemcpyAsync(d_depths, depths, (size_t)nlayers * sizeof(double), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipMemcpyAsync(d_off, src_offset, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipMemcpyAsync(d_dep, src_depth, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    rc = rtmi_trace_device(d_vels, d_depths, nlayers, d_off, d_dep, nsrc, d_t, want_p ? d_p : nullptr, c.d_work,
-                           (int64_t)(c.work_cap * sizeof(double)), c.stream);
+    rc = rtmi_trace_device(d_vels, d_depths, nlayers, d_off, d_dep, nsrc, d_t, want_p ? d_p : nullptr, c.stream);
     if (rc)
         return rc;
     HIP_TRY(hipMemcpyAsync(timeP, d_t, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
@@ -262,10 +253,6 @@ int rtmi_init(int device)
             (void)hipFree(c.d_model);
         if (c.d_src)
             (void)hipFree(c.d_src);
-        if (c.d_work)
-            (void)hipFree(c.d_work);
-        c.d_work = nullptr;
-        c.work_cap = 0;
         if (c.stream)
             (void)hipStreamDestroy(c.stream);
         c.d_model = c.d_src = nullptr;
@@ -278,6 +265,29 @@ int rtmi_init(int device)
     return ensure_ready_locked(c);
 }
 
+int rtmi_set_option(const char *name, int value)
+{
+    if (!name)
+        return fail(RTMI_ERR_BAD_ARG, "NULL option name");
+    Tuning &t = tuning();
+    if (!strcmp(name, "path")) {
+        if (value < 0 || value > 2)
+            return fail(RTMI_ERR_BAD_ARG, "path must be 0 (auto), 1 (plain) or 2 (fused)");
+        t.force_path = value;
+    } else if (!strcmp(name, "waves_per_simd")) {
+        if (value < 1 || value > 8)
+            return fail(RTMI_ERR_BAD_ARG, "waves_per_simd must be in [1, 8]");
+        t.solve_waves = value;
+    } else if (!strcmp(name, "refill_min")) {
+        if (value < 1 || value > 64)
+            return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
+        t.refill_min = value;
+    } else {
+        return fail(RTMI_ERR_BAD_ARG, "unknown option %s", name);
+    }
+    return RTMI_OK;
+}
+
 int rtmi_device_cus(void)
 {
     Context &c = ctx();
@@ -287,16 +297,8 @@ int rtmi_device_cus(void)
     return c.cus;
 }
 
-int64_t rtmi_trace_work_bytes(int64_t nsrc, int nlayers)
-{
-    if (nsrc < 0 || nlayers < 1 || nlayers > RTMI_MAX_LAYERS)
-        return 0;
-    return (int64_t)rtmi_binned_work_bytes(nsrc, nlayers);
-}
-
 int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
-                      const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final, void *d_work,
-                      int64_t work_bytes, void *stream)
+                      const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final, void *stream)
 {
     int rc = check_model(nlayers);
     if (rc)
@@ -305,17 +307,14 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         return fail(RTMI_ERR_BAD_ARG, "nsrc < 0");
     if (nsrc == 0)
         return RTMI_OK;
-    if (nsrc > 0xFFFFFFFFll)
-        return fail(RTMI_ERR_BAD_ARG, "nsrc = %lld exceeds 2^32 - 1 sources per call", (long long)nsrc);
     if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
         return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
-    const Tuning &tn = tuning();
-    const bool have_work = d_work && work_bytes >= rtmi_trace_work_bytes(nsrc, nlayers);
-    const bool binned = have_work && tn.force_path != 1 && (nsrc >= RTMI_BINNED_MIN_NSRC || tn.force_path == 2);
-    if (binned) {
-        HIP_TRY(rtmi_launch_binned(d_vels, d_depths, nlayers, d_src_offset, d_src_depth, nsrc, d_timeP, d_p_final,
-                                   d_work, num_cus_for_current_device(), tn.solve_waves, tn.refill_min,
-                                   (hipStream_t)stream));
+    const Tuning tn = tuning();
+    const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
+    if (fused) {
+        HIP_TRY(rtmi_launch_fused(d_vels, d_depths, nlayers, d_src_offset, d_src_depth, nsrc, d_timeP, d_p_final,
+                                  num_cus_for_current_device(), tn.solve_waves, tn.refill_min,
+                                  (hipStream_t)stream));
         return RTMI_OK;
     }
     rtmi::TraceArgs a;

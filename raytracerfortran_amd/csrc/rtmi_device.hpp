@@ -215,9 +215,12 @@ __device__ __forceinline__ void lane_start(Lane &s, double p0)
 __device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
 {
     const double safe = s.vmi - 1e-10;  // 1/maxval(V)-(1d-10)      (:142, :388)
+    // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294) are the same quotient of the
+    // same two operands: divide once, ahead of the (lane-divergent) state dispatch.
+    const double q = f / fp;
     bool newton_step = (s.st == ST_NEWTON);
     if (s.st == ST_INIT) {
-        const double check_x = s.xe - f / fp;
+        const double check_x = s.xe - q;
         if (f < 0.0 || check_x < safe) {
             s.st = ST_NEWTON;  // solve(p0): its first costFunc/costFunc_Prime pair is this one
             s.k = 1;
@@ -248,7 +251,7 @@ __device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
         if (f == 0.0) {
             done = true;
         } else {
-            const double check_x = s.xb - f / fp;
+            const double check_x = s.xb - q;
             if (check_x < safe) {
                 s.xb = s.xe;
                 done = true;
@@ -281,7 +284,7 @@ __device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
             s.conv = true;
             s.st = ST_DONE;
         } else {
-            s.x = s.x - f / fp;
+            s.x = s.x - q;
             if (s.x > s.vmi)
                 s.x = s.vmi - 1e-9;
             s.xe = s.x;

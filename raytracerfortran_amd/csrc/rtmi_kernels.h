@@ -26,34 +26,28 @@ struct TraceArgs {
     double *d_partial;    // [nmodels][grid_x] per-workgroup sums of squared residuals
 };
 
-// Arguments of the binned pipeline (one model).  Workspace arrays are carved by rtmi_launch_binned.
-#define RTMI_KEY_CONV (1 << 20)      // key[k] bit: the solver reported convergence
-#define RTMI_KEY_NL_MASK 0xFFFFF     // key[k] low bits: nl (1-based layer of the source), 0 = already reported
-struct BinArgs {
+// Arguments of the fused large-NSrc kernel (one model).
+#define RTMI_SLOT_BYTES 32  // LDS per queued record: offset, depth, p (f64) + key, nl scratch (u32)
+struct FusedArgs {
     const double *d_vels;
     const double *d_depths;
     int nlayers;
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
+    int slots;                   // records a wave holds in LDS per round (multiple of 64)
     const double *d_src_offset;
     const double *d_src_depth;
     int64_t nsrc;
     double *d_timeP;
-    double *d_pfin;              // final ray parameter per source, input order (user buffer or workspace)
-    uint32_t *hist;              // [nlayers+2] sources per nl
-    uint32_t *cursor;            // [nlayers+2] running fill of each bin
-    int32_t *key;                // [nsrc] nl | RTMI_KEY_CONV, input order
-    double *bR, *bz, *bp0;       // [nsrc] offset, depth, start value in binned order
-    uint32_t *bidx;              // [nsrc] input index of the binned record
-    int32_t *bnl;                // [nsrc] nl of the binned record
+    double *d_p_final;           // or NULL
 };
 
 }  // namespace rtmi
 
 extern "C" {
-size_t rtmi_binned_work_bytes(int64_t nsrc, int nlayers);
-hipError_t rtmi_launch_binned(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
-                              const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final,
-                              void *d_work, int num_cus, int waves_per_simd, int refill_min, hipStream_t stream);
+int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *slots, size_t *lds_bytes);
+hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
+                             const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final,
+                             int num_cus, int waves_per_simd, int refill_min, hipStream_t stream);
 int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);
 hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
                              hipStream_t stream);

@@ -10,27 +10,30 @@
 // sequence: the kernels reproduce the reference's arithmetic operation for operation in IEEE
 // fp64 (rtmi_device.hpp).  THIS FILE MUST BE COMPILED WITH -ffp-contract=off (build.py does).
 //
-// Two paths (DESIGN.md has the measurements):
+// Two kernels (DESIGN.md has the measurements):
 //
-//  (1) trace_kernel -- one launch, one lane per source in input order.  The three solver branches
-//      of GetPTime are folded into one per-lane state machine around a single wave-converged
-//      "evaluate f and f' at x" loop (one sqrt + two divides per layer; f and f' share the sqrt,
-//      solvebst's duplicate costFunc call is evaluated once).  Used for small NSrc and for the
-//      many-models batch.  Its cost is set by the slowest lane of each wave: deepest source x most
-//      evaluations.
+//  (1) trace_kernel -- one lane per source in input order.  The three solver branches of GetPTime
+//      are folded into one per-lane state machine around a single wave-converged "evaluate f and
+//      f' at x" loop (one sqrt + two divides per layer; f and f' share the sqrt, solvebst's
+//      duplicate costFunc call is evaluated once).  Used for small NSrc and for the many-models
+//      batch (grid.y = model).  Its cost is set by the slowest lane of each wave: deepest source x
+//      most evaluations, i.e. ~20 % of the executed lane-instructions are useful on random input.
 //
-//  (2) the binned pipeline for large NSrc -- same arithmetic per source, scheduled so that lanes
-//      stay busy:
-//        bin_count_kernel    nl per source + histogram of nl
-//        bin_scatter_kernel  counting sort by DESCENDING nl (so a wave's layer loop has one trip
-//                            count), p0 per source, straight top-layer rays finished here
-//        solve_kernel        persistent waves; a lane that finishes its source immediately takes
-//                            the next one of its wave's queue (lane refill), so the evaluation loop
-//                            runs with nearly all 64 lanes active instead of waiting for the
-//                            slowest source
-//        time_kernel         t from the final ray parameter, in input order (coalesced)
-//      HBM traffic rises from 24 to ~150 B per source, still a few percent of the HBM roof; the
-//      kernel is fp64-VALU bound and this trade buys ~3x lane utilisation.
+//  (2) fused_kernel -- the large-NSrc path, same arithmetic per source, scheduled so that lanes
+//      stay busy.  Each wave owns an interleaved set of 64-source chunks and keeps their records in
+//      LDS:
+//        a. load: coalesced reads of offset/depth, whichLayer, start value p0, and a wave-local
+//           counting sort of the records by DESCENDING layer index (LDS atomics, 64 bins), so that
+//           the layer loop of the wave has one trip count at any time; straight top-layer rays are
+//           finished here;
+//        b. solve: a lane that finishes its source takes the next record of the wave's queue
+//           (lane refill, once `refill_min` lanes are idle), so the evaluation loop runs with
+//           nearly all 64 lanes active instead of waiting for the slowest source; no global memory
+//           traffic inside the loop (records and results live in LDS);
+//        c. time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written
+//           to timeP (the only HBM write).
+//      HBM traffic stays at the algorithmic 24 B per source (offset/depth are read a second time
+//      from L2 in the sort's second pass); no workspace, no global atomics, deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -144,200 +147,176 @@ __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, c
 }
 
 // =============================================================================================
-// (2) binned pipeline
+// (2) fused large-NSrc kernel: wave-local sort by layer + lane refill from LDS
 // =============================================================================================
 
-// Bin b = nl (1 .. nlayers+1).  hist/cursor have nlayers+2 entries, zeroed before the launch.
-__global__ __launch_bounds__(RTMI_BLOCK) void bin_count_kernel(BinArgs a)
+// Orders LDS accesses of the lanes of ONE wave (the per-wave regions are private to a wave, so no
+// workgroup barrier is needed -- and none could be used: waves run different trip counts).
+__device__ __forceinline__ void wave_lds_sync()
 {
-    extern __shared__ double lds[];
-    const LayerTable t = carve_table(lds, a.nlayers);
-    uint32_t *lh = reinterpret_cast<uint32_t *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1));
-    const int nb = a.nlayers + 2;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x)
-        lh[i] = 0;
-    stage_model(t, a.d_vels, a.d_depths, a.nlayers);  // ends with a barrier
-
-    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
-        const bool valid = k < a.nsrc;
-        const double z = valid ? a.d_src_depth[k] : 0.0;
-        const int nl = which_layer(t, a.nlayers, z);
-        if (valid) {
-            a.key[k] = nl;
-            atomicAdd(&lh[nl], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += blockDim.x)
-        if (lh[i])
-            atomicAdd(&a.hist[i], lh[i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Counting sort by descending nl + per-source start values.  One tile of RTMI_BLOCK sources per
-// workgroup iteration; positions inside a bin are handed out by atomics (any order is fine: every
-// source's arithmetic is independent of where it is processed).
-__global__ __launch_bounds__(RTMI_BLOCK) void bin_scatter_kernel(BinArgs a)
+// Sort bin of a layer index: exact for <= 63 layers, proportional above.  Monotone in nl.
+__device__ __forceinline__ int bin_of(int nl, int nl_max)
 {
-    extern __shared__ double lds[];
-    const LayerTable t = carve_table(lds, a.nlayers);
-    const int nb = a.nlayers + 2;
-    uint32_t *base = reinterpret_cast<uint32_t *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1));  // bin start
-    uint32_t *lc = base + nb;                                                                   // tile count
-    uint32_t *gb = lc + nb;                                                                     // tile start
-    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;  // descending nl: deepest bin first, straight rays (nl == 1) last
-        for (int b = nb - 1; b >= 0; --b) {
-            base[b] = acc;
-            acc += a.hist[b];
-        }
-    }
-    for (int i = threadIdx.x; i < nb; i += blockDim.x)
-        lc[i] = 0;
-    __syncthreads();
-
-    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
-        const bool valid = k < a.nsrc;
-        int nl = 1;
-        uint32_t rank = 0;
-        double R = 1.0, z = 1.0;
-        if (valid) {
-            nl = a.key[k];
-            R = a.d_src_offset[k];
-            z = a.d_src_depth[k];
-            rank = atomicAdd(&lc[nl], 1u);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-            const uint32_t c = lc[i];
-            if (c)
-                gb[i] = base[i] + atomicAdd(&a.cursor[i], c);
-        }
-        __syncthreads();
-        if (valid) {
-            if (nl == 1) {
-                // straight ray in the top layer (:94-97): finished here
-                a.d_timeP[k] = sqrt(z * z + R * R) / t.V[0];
-                if (a.d_pfin)
-                    a.d_pfin[k] = __builtin_nan("");
-            } else {
-                const int il = nl - 1;
-                const double p0 = initial_p0(t, il, R, z);
-                const uint32_t pos = gb[nl] + rank;
-                a.bR[pos] = R;
-                a.bz[pos] = z;
-                a.bp0[pos] = p0;
-                a.bidx[pos] = (uint32_t)k;
-                a.bnl[pos] = nl;
-                if (p0 != p0) {
-                    // the reference never returns for this source (NaN/Inf data); report -999
-                    a.d_timeP[k] = -999.0;
-                    if (a.d_pfin)
-                        a.d_pfin[k] = p0;
-                    a.key[k] = 0;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += blockDim.x)
-            lc[i] = 0;
-        __syncthreads();
-    }
+    return nl_max <= 63 ? nl : (int)(((long long)nl * 63) / nl_max);
 }
 
-// Persistent waves with lane refill.  Wave w owns chunks w, w + nwaves, w + 2 nwaves, ... of 64
-// consecutive sources in binned order (interleaving gives every wave the same mix of bins); a lane
-// whose source is finished takes the next entry of that queue once `refill_min` lanes are idle.
-__global__ __launch_bounds__(RTMI_BLOCK) void solve_kernel(BinArgs a)
+#define RTMI_RK_LOC_MASK 0xFFFu       // rk: local source index within the wave's round
+#define RTMI_RK_NL_SHIFT 12           // rk: nl in bits 12..27
+#define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
+
+template <bool WANT_P>
+__global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
 {
     extern __shared__ double lds[];
     const LayerTable t = carve_table(lds, a.nlayers);
     stage_model(t, a.d_vels, a.d_depths, a.nlayers);
 
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (RTMI_BLOCK / 64) + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const int slots = a.slots;
+    char *wbase = reinterpret_cast<char *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1)) +
+                  (size_t)wib * ((size_t)slots * RTMI_SLOT_BYTES + 64 * sizeof(uint32_t));
+    double *rR = reinterpret_cast<double *>(wbase);  // offset            } records of the wave's current round,
+    double *rz = rR + slots;                          // depth             } sorted by descending layer
+    double *rp = rz + slots;                          // p0, later p_final }
+    uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 12 | conv << 31
+    uint32_t *tnl = rk + slots;                       // nl per local index (between the two sort passes)
+    uint32_t *hist = tnl + slots;                     // 64 bins
+
+    const int64_t w = (int64_t)blockIdx.x * (RTMI_BLOCK / 64) + wib;
     const int64_t nwaves = (int64_t)gridDim.x * (RTMI_BLOCK / 64);
-    const int64_t n_solve = a.nsrc - (int64_t)a.hist[1];  // everything but the straight rays
-    const int64_t nchunks = (n_solve + 63) / 64;
-    const int qend = (int)((nchunks + nwaves - 1) / nwaves) * 64;  // queue length of every wave
-    int qnext = 0;
+    const int64_t nchunks = (a.nsrc + 63) / 64;
+    const int CH = slots / 64;
+    const int nl_max = a.nlayers + 1;
 
-    Lane s;
-    s.st = ST_DONE;
-    s.nfull = 0;
-    s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = 0.0;
-    s.k = 0;
-    s.conv = false;
-    uint32_t orig = 0;
-    int nl = 0;
-    int nfull_wave = 0;
+    for (int64_t j0 = 0; w + j0 * nwaves < nchunks; j0 += CH) {
+        // ---- a. load + wave-local counting sort -------------------------------------------------
+        hist[lane] = 0;
+        wave_lds_sync();
+        for (int c = 0; c < CH; ++c) {
+            const int64_t chunk = w + (j0 + c) * nwaves;
+            if (chunk >= nchunks)
+                break;
+            const int64_t k = chunk * 64 + lane;
+            const bool valid = k < a.nsrc;
+            const double z = valid ? a.d_src_depth[k] : 0.0;
+            int nl = which_layer(t, a.nlayers, z);
+            if (!valid)
+                nl = 1;  // like a straight ray: never queued
+            tnl[c * 64 + lane] = (uint32_t)nl;
+            if (nl > 1)
+                atomicAdd(&hist[bin_of(nl, nl_max)], 1u);
+        }
+        wave_lds_sync();
+        uint32_t incl = hist[lane];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += o;
+        }
+        const int nq = (int)__shfl(incl, 63, 64);  // records queued this round
+        wave_lds_sync();
+        hist[lane] = (uint32_t)nq - incl;  // first slot of bin `lane` when bins are laid out descending
+        wave_lds_sync();
+        for (int c = 0; c < CH; ++c) {
+            const int64_t chunk = w + (j0 + c) * nwaves;
+            if (chunk >= nchunks)
+                break;
+            const int64_t k = chunk * 64 + lane;
+            if (k < a.nsrc) {
+                const int nl = (int)tnl[c * 64 + lane];
+                const double R = a.d_src_offset[k];
+                const double z = a.d_src_depth[k];
+                if (nl == 1) {
+                    // straight ray in the top layer (:94-97): finished here
+                    a.d_timeP[k] = sqrt(z * z + R * R) / t.V[0];
+                    if (WANT_P)
+                        a.d_p_final[k] = __builtin_nan("");
+                } else {
+                    const double p0 = initial_p0(t, nl - 1, R, z);
+                    const uint32_t pos = atomicAdd(&hist[bin_of(nl, nl_max)], 1u);
+                    rR[pos] = R;
+                    rz[pos] = z;
+                    rp[pos] = p0;
+                    rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
+                }
+            }
+        }
+        wave_lds_sync();
 
-    for (;;) {
-        const unsigned long long idle = __ballot(s.st == ST_DONE);
-        const int nidle = __popcll(idle);
-        if (qnext < qend && nidle >= a.refill_min) {
-            if (s.st == ST_DONE) {
-                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-                const int q = qnext + rank;
-                if (q < qend) {
-                    const int64_t pos = (wave + (int64_t)(q >> 6) * nwaves) * 64 + (q & 63);
-                    if (pos < n_solve) {
-                        const double p0 = a.bp0[pos];
-                        if (p0 == p0) {  // NaN: already reported by bin_scatter_kernel
-                            nl = a.bnl[pos];
-                            orig = a.bidx[pos];
-                            lane_setup(s, t, nl - 1, a.bR[pos], a.bz[pos]);
+        // ---- b. solve with lane refill ----------------------------------------------------------
+        Lane s;
+        s.st = ST_DONE;
+        s.nfull = 0;
+        s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = 0.0;
+        s.k = 0;
+        s.conv = false;
+        int slot = 0;
+        int qnext = 0;
+        int nfull_wave = 0;
+        for (;;) {
+            const unsigned long long idle = __ballot(s.st == ST_DONE);
+            const int nidle = __popcll(idle);
+            if (qnext < nq && nidle >= a.refill_min) {
+                if (s.st == ST_DONE) {
+                    const int q = qnext + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (q < nq) {
+                        const double p0 = rp[q];
+                        if (p0 == p0) {  // NaN p0: the reference never returns; stays unconverged -> -999
+                            const int nl = (int)((rk[q] >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                            slot = q;
+                            lane_setup(s, t, nl - 1, rR[q], rz[q]);
                             lane_start(s, p0);
                         }
                     }
                 }
+                qnext += nidle;
+                nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
             }
-            qnext += nidle;
-            nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
+            if (__all(s.st == ST_DONE)) {
+                if (qnext >= nq)
+                    break;
+                continue;  // all 64 lanes idle: the next trip refills
+            }
+            double f, fp;
+            eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
+            const bool was_busy = (s.st != ST_DONE);
+            lane_advance(s, f, fp);
+            if (was_busy && s.st == ST_DONE) {
+                rp[slot] = s.x;
+                if (s.conv)
+                    rk[slot] |= RTMI_RK_CONV;
+            }
         }
-        if (__all(s.st == ST_DONE)) {
-            if (qnext >= qend)
-                break;
-            continue;  // nidle == 64 >= refill_min: the next trip refills
-        }
+        wave_lds_sync();
 
-        double f, fp;
-        eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
-        const bool was_busy = (s.st != ST_DONE);
-        lane_advance(s, f, fp);
-        if (was_busy && s.st == ST_DONE) {
-            a.d_pfin[orig] = s.x;
-            a.key[orig] = nl | (s.conv ? RTMI_KEY_CONV : 0);
+        // ---- c. travel times in sorted order ----------------------------------------------------
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int q = q0 + lane;
+            const bool valid = q < nq;
+            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu) - 1;
+            const double p = valid ? rp[q] : 0.0;
+            const double z = valid ? rz[q] : 1.0;
+            const int nfw = wave_max_i32(valid ? il : 0);
+            double tt = travel_time(t, p, il, nfw, il, z);
+            if (!(key & RTMI_RK_CONV))
+                tt = -999.0;
+            if (valid) {
+                const int loc = (int)(key & RTMI_RK_LOC_MASK);
+                const int64_t k = (w + (j0 + (loc >> 6)) * nwaves) * 64 + (loc & 63);
+                a.d_timeP[k] = tt;
+                if (WANT_P)
+                    a.d_p_final[k] = p;
+            }
         }
-    }
-}
-
-// t = sum H_i / (V_i sqrt(1 - p^2 V_i^2)) for every traced source, input order.
-__global__ __launch_bounds__(RTMI_BLOCK) void time_kernel(BinArgs a)
-{
-    extern __shared__ double lds[];
-    const LayerTable t = carve_table(lds, a.nlayers);
-    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
-    const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
-        const bool valid = k < a.nsrc;
-        const int kv = valid ? a.key[k] : 0;
-        const int nl = kv & RTMI_KEY_NL_MASK;
-        const bool traced = nl > 1;  // 1: straight ray, 0: reported by bin_scatter_kernel
-        const int il = traced ? nl - 1 : 1;
-        const double z = traced ? a.d_src_depth[k] : 1.0;
-        const double p = traced ? a.d_pfin[k] : 0.0;
-        const int nfull_wave = wave_max_i32(traced ? il : 0);
-        double tt = travel_time(t, p, il, nfull_wave, il, z);
-        if (!(kv & RTMI_KEY_CONV))
-            tt = -999.0;
-        if (traced)
-            a.d_timeP[k] = tt;
+        wave_lds_sync();
     }
 }
 
@@ -393,24 +372,61 @@ extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, c
     return hipGetLastError();
 }
 
-extern "C" size_t rtmi_binned_work_bytes(int64_t nsrc, int nlayers)
+// Geometry of the fused kernel: `waves_per_simd` resident waves on each SIMD, every wave's round fits its
+// LDS share.  Returns workgroups; *slots = records per wave and round (multiple of 64), *lds_bytes per workgroup.
+extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *slots,
+                                   size_t *lds_bytes)
 {
-    // hist | cursor (u32 each, nlayers+2, padded) | key i32 | bidx u32 | bnl i32 | bR bz bp0 pfin f64
-    const size_t nb = ((size_t)nlayers + 2 + 63) / 64 * 64;
-    const size_t n = ((size_t)nsrc + 63) / 64 * 64;
-    return 2 * nb * sizeof(uint32_t) + n * (3 * sizeof(uint32_t) + 4 * sizeof(double));
+    const int wpb = RTMI_BLOCK / 64;
+    const int64_t nchunks = (nsrc + 63) / 64;
+    if (waves_per_simd < 1)
+        waves_per_simd = 1;
+    if (waves_per_simd > 8)
+        waves_per_simd = 8;
+    int64_t nblocks = (int64_t)num_cus * waves_per_simd;  // one 4-wave workgroup per CU per wave-per-SIMD
+    if (nblocks * wpb > nchunks)
+        nblocks = (nchunks + wpb - 1) / wpb;
+    if (nblocks < 1)
+        nblocks = 1;
+    const int64_t nwaves = nblocks * wpb;
+    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (nlayers + 1) * sizeof(double);
+    // LDS share of one workgroup when `waves_per_simd` workgroups are resident on a CU (160 KiB per CU)
+    const size_t lds_cu = 160 * 1024;
+    size_t share = lds_cu / waves_per_simd;
+    if (share < table + wpb * (64 * RTMI_SLOT_BYTES + 256))
+        share = table + wpb * (64 * RTMI_SLOT_BYTES + 256);  // very large tables: fewer resident workgroups
+    int64_t max_slots = (int64_t)((share - table) / wpb - 256) / RTMI_SLOT_BYTES / 64 * 64;
+    if (max_slots > 4032)
+        max_slots = 4032;  // 12-bit local index
+    if (max_slots < 64)
+        max_slots = 64;
+    int64_t want = (nchunks + nwaves - 1) / nwaves * 64;
+    if (want > max_slots)
+        want = max_slots;
+    *slots = (int)want;
+    *lds_bytes = table + (size_t)wpb * ((size_t)want * RTMI_SLOT_BYTES + 256);
+    return (int)nblocks;
 }
 
-extern "C" hipError_t rtmi_launch_binned(const double *d_vels, const double *d_depths, int nlayers,
-                                         const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
-                                         double *d_timeP, double *d_p_final, void *d_work, int num_cus,
-                                         int waves_per_simd, int refill_min, hipStream_t stream)
+extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers,
+                                        const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                                        double *d_timeP, double *d_p_final, int num_cus, int waves_per_simd,
+                                        int refill_min, hipStream_t stream)
 {
     using namespace rtmi;
-    const size_t nb = ((size_t)nlayers + 2 + 63) / 64 * 64;
-    const size_t n = ((size_t)nsrc + 63) / 64 * 64;
-    char *w = static_cast<char *>(d_work);
-    BinArgs a;
+    static bool attr_set = false;
+    if (!attr_set) {
+        // dynamic LDS above 64 KiB needs the opt-in (large layer tables)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    FusedArgs a;
     a.d_vels = d_vels;
     a.d_depths = d_depths;
     a.nlayers = nlayers;
@@ -419,40 +435,15 @@ extern "C" hipError_t rtmi_launch_binned(const double *d_vels, const double *d_d
     a.d_src_depth = d_src_depth;
     a.nsrc = nsrc;
     a.d_timeP = d_timeP;
-    a.hist = reinterpret_cast<uint32_t *>(w);
-    a.cursor = a.hist + nb;
-    w += 2 * nb * sizeof(uint32_t);
-    a.bR = reinterpret_cast<double *>(w);
-    a.bz = a.bR + n;
-    a.bp0 = a.bz + n;
-    double *pfin_ws = a.bp0 + n;
-    w += 4 * n * sizeof(double);
-    a.key = reinterpret_cast<int32_t *>(w);
-    a.bidx = reinterpret_cast<uint32_t *>(w) + n;
-    a.bnl = reinterpret_cast<int32_t *>(w) + 2 * n;
-    a.d_pfin = d_p_final ? d_p_final : pfin_ws;
-
-    hipError_t e = hipMemsetAsync(a.hist, 0, 2 * nb * sizeof(uint32_t), stream);
-    if (e != hipSuccess)
-        return e;
-    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (nlayers + 1) * sizeof(double);
-    const size_t bins = (size_t)3 * (nlayers + 2) * sizeof(uint32_t);
-    const int64_t ntiles = (nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
-    int64_t gtiles = (int64_t)num_cus * 8;
-    if (gtiles > ntiles)
-        gtiles = ntiles;
-    const dim3 block(RTMI_BLOCK, 1, 1);
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)gtiles), block, table + bins, stream, a);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)gtiles), block, table + bins, stream, a);
-    // solve: waves_per_simd persistent waves on each of the 4 SIMDs of every CU, never more waves
-    // than chunks
-    const int64_t nchunks = (nsrc + 63) / 64;
-    int64_t gsolve = (int64_t)num_cus * waves_per_simd;  // workgroups of 4 waves
-    if (gsolve * (RTMI_BLOCK / 64) > nchunks)
-        gsolve = (nchunks + RTMI_BLOCK / 64 - 1) / (RTMI_BLOCK / 64);
-    if (gsolve < 1)
-        gsolve = 1;
-    hipLaunchKernelGGL(solve_kernel, dim3((unsigned)gsolve), block, table, stream, a);
-    hipLaunchKernelGGL(time_kernel, dim3((unsigned)gtiles), block, table, stream, a);
+    a.d_p_final = d_p_final;
+    size_t lds_bytes = 0;
+    const int nblocks = rtmi_fused_geometry(nsrc, nlayers, num_cus, waves_per_simd, &a.slots, &lds_bytes);
+    if (lds_bytes > 160 * 1024)
+        return hipErrorInvalidValue;
+    const dim3 grid(nblocks, 1, 1), block(RTMI_BLOCK, 1, 1);
+    if (d_p_final)
+        hipLaunchKernelGGL((fused_kernel<true>), grid, block, lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((fused_kernel<false>), grid, block, lds_bytes, stream, a);
     return hipGetLastError();
 }

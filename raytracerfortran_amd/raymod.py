@@ -44,9 +44,8 @@ SIGNATURES = {
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
     "rtmi_device_cus": (ctypes.c_int, []),
-    "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
-                                         ctypes.c_int64, _vp]),
-    "rtmi_trace_work_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
+    "rtmi_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_batch_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64,
                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
@@ -97,6 +96,11 @@ def _check(rc: int) -> None:
 
 def init(device: int = 0) -> None:
     _check(load_library().rtmi_init(int(device)))
+
+
+def set_option(name: str, value: int) -> None:
+    """Scheduling knobs of trace_device ("path", "waves_per_simd", "refill_min"); see include/rtmi.h."""
+    _check(load_library().rtmi_set_option(name.encode(), int(value)))
 
 
 def _as_f64(a, n=None, name="array"):
@@ -198,17 +202,9 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(s.cuda_stream)
 
 
-def trace_work(nsrc: int, nlayers: int, device):
-    """Scratch tensor for trace_device's binned pipeline (rtmi_trace_work_bytes); reuse it across calls."""
-    import torch
-    nbytes = int(load_library().rtmi_trace_work_bytes(int(nsrc), int(nlayers)))
-    return torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=device)
-
-
-def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, work=None, stream=None):
+def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, stream=None):
     """One forward evaluation on resident data (rtmi_trace_device).  Asynchronous on `stream`
-    (default: torch's current stream).  `work` (from trace_work) enables the binned pipeline for
-    large source sets; results are identical with and without it.  Returns timeP."""
+    (default: torch's current stream).  Returns timeP."""
     import torch
     lib = load_library()
     nlayers = int(depths.numel())
@@ -224,9 +220,7 @@ def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, 
     f64 = torch.float64
     _check(lib.rtmi_trace_device(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers,
                                  _ptr(src_offset, f64, "src_offset"), _ptr(src_depth, f64, "src_depth"), n,
-                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"),
-                                 _ptr(work, f64, "work"), int(work.numel() * 8) if work is not None else 0,
-                                 _stream_ptr(stream)))
+                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"), _stream_ptr(stream)))
     return timeP
 
 

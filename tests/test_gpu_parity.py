@@ -176,8 +176,7 @@ def test_trace_device_full_c2(rt, O):
     dv, dd = torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda")
     do, dz = torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")
     p = torch.empty(n, dtype=torch.float64, device="cuda")
-    work = rt.trace_work(n, d.size, "cuda")
-    t = rt.trace_device(dv, dd, do, dz, p_final=p, work=work)
+    t = rt.trace_device(dv, dd, do, dz, p_final=p)
     torch.cuda.synchronize()
     t = t.cpu().numpy()
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
@@ -189,49 +188,74 @@ def test_trace_device_full_c2(rt, O):
     assert np.array_equal(p[nl > 1], pref[nl > 1])
     # size-independent properties: order independence and determinism
     perm = np.random.default_rng(0).permutation(n)
-    t2 = rt.trace_device(dv, dd, torch.tensor(off[perm], device="cuda"), torch.tensor(dep[perm], device="cuda"),
-                         work=work)
+    t2 = rt.trace_device(dv, dd, torch.tensor(off[perm], device="cuda"), torch.tensor(dep[perm], device="cuda"))
     assert np.array_equal(t2.cpu().numpy(), t[perm])
-    t3 = rt.trace_device(dv, dd, do, dz)  # single-launch kernel on the same data
-    assert np.array_equal(t3.cpu().numpy(), t)
+    t3 = rt.trace_device(dv, dd, torch.tensor(np.sort(off), device="cuda"),
+                         torch.tensor(dep[np.argsort(off)], device="cuda"))  # sorted input: other chunking
+    assert np.array_equal(t3.cpu().numpy(), t[np.argsort(off)])
 
 
-@pytest.mark.parametrize("n", [32768, 40001, 300000])
-def test_binned_pipeline_equals_single_launch(rt, O, n):
-    """With a scratch buffer rtmi_trace_device regroups large source sets by layer and refills lanes as they
-    finish; without it the single-launch kernel runs.  Same arithmetic per source: bit-identical results,
-    final ray parameters included, also with NaN data, straight rays and the -999 sources in the mix."""
+@pytest.mark.parametrize("n", [1, 64, 8192, 40001, 300000])
+@pytest.mark.parametrize("wps,refill", [(3, 16), (1, 1), (8, 64), (5, 7)])
+def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
+    """Large source sets take the fused kernel (wave-local sort by layer, lane refill); small ones the plain
+    one-lane-per-source kernel.  Same arithmetic per source: bit-identical results under every scheduling
+    knob, final ray parameters included, with NaN data, straight rays, interface hits and -999 sources."""
     import torch
     v, d, off, dep = c2_workload(n, seed=77 + n)
-    off[5], dep[9] = np.nan, np.inf
-    dep[100:200] = 10.0          # a run of straight top-layer rays
-    dep[300] = d[-1]             # exactly on the last interface
-    dep[301] = d[3]              # exactly on an inner interface
+    if n > 400:
+        off[5], dep[9] = np.nan, np.inf
+        dep[100:200] = 10.0          # a run of straight top-layer rays
+        dep[300] = d[-1]             # exactly on the last interface
+        dep[301] = d[3]              # exactly on an inner interface
     dv, dd = torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda")
     do, dz = torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")
     p1 = torch.empty(n, dtype=torch.float64, device="cuda")
     p2 = torch.empty(n, dtype=torch.float64, device="cuda")
-    t1 = rt.trace_device(dv, dd, do, dz, p_final=p1).cpu().numpy()
-    work = rt.trace_work(n, d.size, "cuda")
-    t2 = rt.trace_device(dv, dd, do, dz, p_final=p2, work=work).cpu().numpy()
-    t3 = rt.trace_device(dv, dd, do, dz, work=work).cpu().numpy()  # scratch reused, no p_final
+    try:
+        rt.set_option("path", 1)
+        t1 = rt.trace_device(dv, dd, do, dz, p_final=p1).cpu().numpy()
+        rt.set_option("path", 2)
+        rt.set_option("waves_per_simd", wps)
+        rt.set_option("refill_min", refill)
+        t2 = rt.trace_device(dv, dd, do, dz, p_final=p2).cpu().numpy()
+        t3 = rt.trace_device(dv, dd, do, dz).cpu().numpy()  # without p_final
+    finally:
+        rt.set_option("path", 0)
+        rt.set_option("waves_per_simd", 3)
+        rt.set_option("refill_min", 16)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
     assert np.array_equal(t2, ref, equal_nan=True)
-    p2 = p2.cpu().numpy()
+    p1, p2 = p1.cpu().numpy(), p2.cpu().numpy()
     good = (nl > 1) & np.isfinite(off) & np.isfinite(dep)
     assert np.array_equal(p2[good], pref[good]) and np.all(np.isnan(p2[nl == 1]))
-    assert np.array_equal(p1.cpu().numpy()[good], p2[good])
+    assert np.array_equal(p1[good], p2[good])
 
 
-def test_binned_pipeline_many_layers_and_host_path(rt, O):
-    """The drop-in dff_ takes the binned pipeline for NSrc >= 32768 with its own scratch; also 300 interfaces."""
+def test_fused_kernel_many_layers_and_host_path(rt, O):
+    """dff_ takes the fused kernel for NSrc >= 8192; with 300 and 1024 interfaces the sort bins are
+    proportional and the LDS share of a wave shrinks (several rounds per wave)."""
     rng = np.random.default_rng(17)
-    d = np.cumsum(rng.uniform(5, 40, 300))
-    v = rng.uniform(1500, 8000, 301)
-    n = 50000
-    off, dep = rng.uniform(10, 9000, n), rng.uniform(1, d[-1] + 100, n)
-    t = rt.dff(v, d, 300, off, dep, n)["timeP"]
+    for nlay, n in ((300, 50000), (1024, 20000)):
+        d = np.cumsum(rng.uniform(5, 40, nlay))
+        v = rng.uniform(1500, 8000, nlay + 1)
+        off, dep = rng.uniform(10, 9000, n), rng.uniform(1, d[-1] + 100, n)
+        t = rt.dff(v, d, nlay, off, dep, n)["timeP"]
+        assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
+
+
+def test_fused_kernel_several_rounds(rt, O):
+    """More sources than the resident waves hold in LDS at once: every wave runs several load/solve/time rounds."""
+    import torch
+    n = 3_000_001
+    v, d, off, dep = c2_workload(n, seed=3)
+    try:
+        rt.set_option("waves_per_simd", 8)  # smallest LDS share per wave -> most rounds
+        t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
+                            torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
+    finally:
+        rt.set_option("waves_per_simd", 3)
     assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
 
 
