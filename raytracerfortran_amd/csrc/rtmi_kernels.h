@@ -7,6 +7,7 @@
 
 #define RTMI_BLOCK 256          // threads per workgroup (4 waves: one per SIMD of a CU)
 #define RTMI_BLOCKS_PER_CU 16   // grid cap = CUs x this; further tiles are grid-strided
+#define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
 
 namespace rtmi {
 
@@ -33,7 +34,7 @@ struct FusedArgs {
     const double *d_depths;
     int nlayers;
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
-    int slots;                   // records a wave holds in LDS per round (multiple of 64)
+    int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     const double *d_src_offset;
     const double *d_src_depth;
     int64_t nsrc;
@@ -44,7 +45,8 @@ struct FusedArgs {
 }  // namespace rtmi
 
 extern "C" {
-int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *slots, size_t *lds_bytes);
+int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *threads, int *slots,
+                        size_t *lds_bytes);
 hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
                              const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final,
                              int num_cus, int waves_per_simd, int refill_min, hipStream_t stream);

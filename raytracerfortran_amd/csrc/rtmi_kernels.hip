@@ -147,17 +147,8 @@ __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, c
 }
 
 // =============================================================================================
-// (2) fused large-NSrc kernel: wave-local sort by layer + lane refill from LDS
+// (2) fused large-NSrc kernel: CU-wide LDS work queue sorted by layer + lane refill
 // =============================================================================================
-
-// Orders LDS accesses of the lanes of ONE wave (the per-wave regions are private to a wave, so no
-// workgroup barrier is needed -- and none could be used: waves run different trip counts).
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Sort bin of a layer index: exact for <= 63 layers, proportional above.  Monotone in nl.
 __device__ __forceinline__ int bin_of(int nl, int nl_max)
@@ -165,12 +156,14 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
     return nl_max <= 63 ? nl : (int)(((long long)nl * 63) / nl_max);
 }
 
-#define RTMI_RK_LOC_MASK 0xFFFu       // rk: local source index within the wave's round
-#define RTMI_RK_NL_SHIFT 12           // rk: nl in bits 12..27
+#define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
+#define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..28
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 
+// One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
+// chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
 template <bool WANT_P>
-__global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a)
 {
     extern __shared__ double lds[];
     const LayerTable t = carve_table(lds, a.nlayers);
@@ -178,28 +171,29 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
 
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
+    const int nwib = blockDim.x >> 6;
     const int slots = a.slots;
-    char *wbase = reinterpret_cast<char *>(lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1)) +
-                  (size_t)wib * ((size_t)slots * RTMI_SLOT_BYTES + 64 * sizeof(uint32_t));
-    double *rR = reinterpret_cast<double *>(wbase);  // offset            } records of the wave's current round,
-    double *rz = rR + slots;                          // depth             } sorted by descending layer
-    double *rp = rz + slots;                          // p0, later p_final }
-    uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 12 | conv << 31
-    uint32_t *tnl = rk + slots;                       // nl per local index (between the two sort passes)
-    uint32_t *hist = tnl + slots;                     // 64 bins
+    double *rR = lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1);  // offset            } records of the current round,
+    double *rz = rR + slots;                                  // depth             } sorted by descending layer
+    double *rp = rz + slots;                                  // p0, later p_final }
+    uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
+    uint32_t *tnl = rk + slots;                               // nl per local index (between the sort passes)
+    uint32_t *hist = tnl + slots;                             // 64 bins
+    uint32_t *qctl = hist + 64;                               // [0] queue head, [1] records queued
 
-    const int64_t w = (int64_t)blockIdx.x * (RTMI_BLOCK / 64) + wib;
-    const int64_t nwaves = (int64_t)gridDim.x * (RTMI_BLOCK / 64);
+    const int64_t b = blockIdx.x;
+    const int64_t nblocks = gridDim.x;
     const int64_t nchunks = (a.nsrc + 63) / 64;
     const int CH = slots / 64;
     const int nl_max = a.nlayers + 1;
 
-    for (int64_t j0 = 0; w + j0 * nwaves < nchunks; j0 += CH) {
-        // ---- a. load + wave-local counting sort -------------------------------------------------
-        hist[lane] = 0;
-        wave_lds_sync();
-        for (int c = 0; c < CH; ++c) {
-            const int64_t chunk = w + (j0 + c) * nwaves;
+    for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
+        // ---- a. load + workgroup-local counting sort -------------------------------------------
+        if (threadIdx.x < 64)
+            hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int c = wib; c < CH; c += nwib) {
+            const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
@@ -212,20 +206,25 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
             if (nl > 1)
                 atomicAdd(&hist[bin_of(nl, nl_max)], 1u);
         }
-        wave_lds_sync();
-        uint32_t incl = hist[lane];
+        __syncthreads();
+        if (wib == 0) {
+            uint32_t incl = hist[lane];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if (lane >= off)
-                incl += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off)
+                    incl += o;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            hist[lane] = total - incl;  // first slot of bin `lane` when bins are laid out descending
+            if (lane == 0) {
+                qctl[0] = 0;
+                qctl[1] = total;
+            }
         }
-        const int nq = (int)__shfl(incl, 63, 64);  // records queued this round
-        wave_lds_sync();
-        hist[lane] = (uint32_t)nq - incl;  // first slot of bin `lane` when bins are laid out descending
-        wave_lds_sync();
-        for (int c = 0; c < CH; ++c) {
-            const int64_t chunk = w + (j0 + c) * nwaves;
+        __syncthreads();
+        for (int c = wib; c < CH; c += nwib) {
+            const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
@@ -248,9 +247,10 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
                 }
             }
         }
-        wave_lds_sync();
+        __syncthreads();
+        const int nq = (int)qctl[1];
 
-        // ---- b. solve with lane refill ----------------------------------------------------------
+        // ---- b. solve: every wave pulls from the workgroup's queue, lanes refill as they finish ----
         Lane s;
         s.st = ST_DONE;
         s.nfull = 0;
@@ -258,14 +258,19 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
         s.k = 0;
         s.conv = false;
         int slot = 0;
-        int qnext = 0;
+        bool exhausted = false;  // wave-uniform: the queue head has passed nq
         int nfull_wave = 0;
         for (;;) {
             const unsigned long long idle = __ballot(s.st == ST_DONE);
             const int nidle = __popcll(idle);
-            if (qnext < nq && nidle >= a.refill_min) {
+            if (!exhausted && nidle >= a.refill_min) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&qctl[0], (uint32_t)nidle);
+                base = __shfl(base, 0, 64);
+                exhausted = (int)base + nidle >= nq;
                 if (s.st == ST_DONE) {
-                    const int q = qnext + __popcll(idle & ((1ull << lane) - 1ull));
+                    const int q = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
                     if (q < nq) {
                         const double p0 = rp[q];
                         if (p0 == p0) {  // NaN p0: the reference never returns; stays unconverged -> -999
@@ -276,11 +281,10 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
                         }
                     }
                 }
-                qnext += nidle;
                 nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
             }
             if (__all(s.st == ST_DONE)) {
-                if (qnext >= nq)
+                if (exhausted)
                     break;
                 continue;  // all 64 lanes idle: the next trip refills
             }
@@ -294,10 +298,10 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
                     rk[slot] |= RTMI_RK_CONV;
             }
         }
-        wave_lds_sync();
+        __syncthreads();
 
         // ---- c. travel times in sorted order ----------------------------------------------------
-        for (int q0 = 0; q0 < nq; q0 += 64) {
+        for (int q0 = wib * 64; q0 < nq; q0 += nwib * 64) {
             const int q = q0 + lane;
             const bool valid = q < nq;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
@@ -310,13 +314,13 @@ __global__ __launch_bounds__(RTMI_BLOCK) void fused_kernel(FusedArgs a)
                 tt = -999.0;
             if (valid) {
                 const int loc = (int)(key & RTMI_RK_LOC_MASK);
-                const int64_t k = (w + (j0 + (loc >> 6)) * nwaves) * 64 + (loc & 63);
+                const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
                 a.d_timeP[k] = tt;
                 if (WANT_P)
                     a.d_p_final[k] = p;
             }
         }
-        wave_lds_sync();
+        __syncthreads();
     }
 }
 
@@ -372,39 +376,40 @@ extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, c
     return hipGetLastError();
 }
 
-// Geometry of the fused kernel: `waves_per_simd` resident waves on each SIMD, every wave's round fits its
-// LDS share.  Returns workgroups; *slots = records per wave and round (multiple of 64), *lds_bytes per workgroup.
-extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *slots,
-                                   size_t *lds_bytes)
+// Geometry of the fused kernel: one workgroup of 64 x `waves_per_simd` x 4 threads per CU (two for more than 4
+// waves per SIMD), holding as many of its records in LDS as its share of the CU's 160 KiB allows.
+// Returns workgroups; *threads per workgroup, *slots = records per workgroup and round (multiple of 64),
+// *lds_bytes per workgroup.
+extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *threads,
+                                   int *slots, size_t *lds_bytes)
 {
-    const int wpb = RTMI_BLOCK / 64;
     const int64_t nchunks = (nsrc + 63) / 64;
     if (waves_per_simd < 1)
         waves_per_simd = 1;
     if (waves_per_simd > 8)
         waves_per_simd = 8;
-    int64_t nblocks = (int64_t)num_cus * waves_per_simd;  // one 4-wave workgroup per CU per wave-per-SIMD
-    if (nblocks * wpb > nchunks)
-        nblocks = (nchunks + wpb - 1) / wpb;
+    const int wg_per_cu = waves_per_simd > 4 ? 2 : 1;
+    int waves = 4 * ((waves_per_simd + wg_per_cu - 1) / wg_per_cu);  // waves per workgroup, <= 16
+    int64_t nblocks = (int64_t)num_cus * wg_per_cu;
+    if (nblocks > nchunks)
+        nblocks = nchunks;
     if (nblocks < 1)
         nblocks = 1;
-    const int64_t nwaves = nblocks * wpb;
+    const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
+    if (waves > chunks_per_block)
+        waves = (int)chunks_per_block;  // small inputs: no idle waves
     const size_t table = (size_t)RTMI_TABLE_ARRAYS * (nlayers + 1) * sizeof(double);
-    // LDS share of one workgroup when `waves_per_simd` workgroups are resident on a CU (160 KiB per CU)
-    const size_t lds_cu = 160 * 1024;
-    size_t share = lds_cu / waves_per_simd;
-    if (share < table + wpb * (64 * RTMI_SLOT_BYTES + 256))
-        share = table + wpb * (64 * RTMI_SLOT_BYTES + 256);  // very large tables: fewer resident workgroups
-    int64_t max_slots = (int64_t)((share - table) / wpb - 256) / RTMI_SLOT_BYTES / 64 * 64;
-    if (max_slots > 4032)
-        max_slots = 4032;  // 12-bit local index
-    if (max_slots < 64)
-        max_slots = 64;
-    int64_t want = (nchunks + nwaves - 1) / nwaves * 64;
+    const size_t fixed = table + 66 * sizeof(uint32_t) + 8;
+    size_t share = (size_t)160 * 1024 / wg_per_cu;
+    int64_t max_slots = share > fixed + 64 * RTMI_SLOT_BYTES ? (int64_t)((share - fixed) / RTMI_SLOT_BYTES / 64 * 64) : 64;
+    if (max_slots > 8128)
+        max_slots = 8128;  // 13-bit local index
+    int64_t want = chunks_per_block * 64;
     if (want > max_slots)
         want = max_slots;
+    *threads = waves * 64;
     *slots = (int)want;
-    *lds_bytes = table + (size_t)wpb * ((size_t)want * RTMI_SLOT_BYTES + 256);
+    *lds_bytes = fixed + (size_t)want * RTMI_SLOT_BYTES;
     return (int)nblocks;
 }
 
@@ -437,10 +442,11 @@ extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_de
     a.d_timeP = d_timeP;
     a.d_p_final = d_p_final;
     size_t lds_bytes = 0;
-    const int nblocks = rtmi_fused_geometry(nsrc, nlayers, num_cus, waves_per_simd, &a.slots, &lds_bytes);
+    int threads = 0;
+    const int nblocks = rtmi_fused_geometry(nsrc, nlayers, num_cus, waves_per_simd, &threads, &a.slots, &lds_bytes);
     if (lds_bytes > 160 * 1024)
         return hipErrorInvalidValue;
-    const dim3 grid(nblocks, 1, 1), block(RTMI_BLOCK, 1, 1);
+    const dim3 grid(nblocks, 1, 1), block(threads, 1, 1);
     if (d_p_final)
         hipLaunchKernelGGL((fused_kernel<true>), grid, block, lds_bytes, stream, a);
     else
