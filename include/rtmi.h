@@ -86,7 +86,7 @@ int rtmi_device_cus(void);
 /*
  * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
  *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel
- *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 3)
+ *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
  * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN.
  */
@@ -132,6 +132,24 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
                             const double *d_obs, const double *d_sd, double *d_logL, void *d_work,
                             void *stream);
 int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc);
+
+/*
+ * Diagnostic used by the parity tests: the kernels evaluate sqrt and divide with the compiler's
+ * expansions minus their exponent-range handling when all operands of a wave are inside a guarded
+ * range.  This compares those forms bit for bit with the plain operators on caller-
+ * supplied operands: d_mismatch[0] += sqrt mismatches over d_w, d_mismatch[1] += divide mismatches
+ * over (d_num, d_den).  d_mismatch (2 x uint64) must be zeroed by the caller.  All device pointers.
+ */
+int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                           unsigned long long *d_mismatch, void *stream);
+
+/*
+ * Diagnostic: while d_stamps != NULL, every fused-kernel launch of rtmi_trace_device writes, per
+ * workgroup, the shader-clock ticks at {start, sorted, solved, times written} of its first round to
+ * d_stamps[36*workgroup + 0..3], and per wave w {queue seen empty, last source finished} to
+ * d_stamps[36*workgroup + 4 + 2w, + 5 + 2w] (device buffer of 36 x 8 B x 2 x CUs).  NULL switches off.
+ */
+int rtmi_debug_stamps(unsigned long long *d_stamps);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Host-side helpers of the drop-in path.

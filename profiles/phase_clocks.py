@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Phase shares of the fused kernel from in-kernel clocks (diagnostic build path: rtmi_debug_stamps)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracerfortran_amd as rt
+import bench
+lib = rt.load_library(); rt.init(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+v, d, off, dep = bench.c2_workload(n)
+dev = "cuda"
+dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
+st = torch.zeros(36 * 512, dtype=torch.int64, device=dev)
+for _ in range(3):
+    rt.trace_device(dv, dd, do, dz)
+lib.rtmi_debug_stamps(ctypes.c_void_p(st.data_ptr()))
+rt.trace_device(dv, dd, do, dz)
+torch.cuda.synchronize()
+lib.rtmi_debug_stamps(None)
+full = st.cpu().numpy().reshape(-1, 36)
+full = full[full[:, 0] != 0]
+s = full[:, :4]
+t0 = s[:, 0].min()
+print("workgroups", len(s))
+for name, a, b in (("load+sort", 0, 1), ("solve", 1, 2), ("time", 2, 3), ("total", 0, 3)):
+    dur = (s[:, b] - s[:, a]).astype(float)
+    print(f"{name:10s} ticks: mean {dur.mean():10.0f}  min {dur.min():10.0f}  max {dur.max():10.0f}")
+print("start skew ticks: max", (s[:, 0] - t0).max(), " end spread: min", (s[:, 3] - t0).min(), "max", (s[:, 3] - t0).max())
+sol = (s[:, 2] - s[:, 1]).astype(float)
+for x in range(8):
+    g = sol[x::8]
+    print(f"blockIdx%8={x}: solve mean {g.mean():9.0f} min {g.min():9.0f} max {g.max():9.0f}")
+# per-block work estimate from the oracle's counters (evaluations x layers)
+from oracle import oracle as O
+nb = len(s)
+nch = (n + 63) // 64
+work = np.zeros(nb)
+tt, p, nl = O.oracle_dff(v, d, off, dep, want_p=True)
+# cheap proxy: sum of nl per block (layers per evaluation); evaluations per source are not exported
+for b in range(nb):
+    idx = np.concatenate([np.arange(c * 64, min((c + 1) * 64, n)) for c in range(b, nch, nb)])
+    work[b] = nl[idx].sum()
+print("corr(solve ticks, sum nl) =", np.corrcoef(sol, work)[0, 1], " sum-nl cv =", work.std() / work.mean())
+
+wv = full[:, 4:].reshape(len(full), 16, 2).astype(float)
+used = wv[:, :, 1] > 0
+dry = np.where(used, wv[:, :, 0], np.nan) - full[:, 1:2]      # since solve start
+fin = np.where(used, wv[:, :, 1], np.nan) - full[:, 1:2]
+print("waves per workgroup:", used.sum(1).mean())
+print("queue seen empty (first wave)  mean %.0f   (last wave) mean %.0f" % (np.nanmin(dry, 1).mean(), np.nanmax(dry, 1).mean()))
+print("wave finished        (first)   mean %.0f   (last)      mean %.0f" % (np.nanmin(fin, 1).mean(), np.nanmax(fin, 1).mean()))
+print("mean over waves of (finish - empty): %.0f ticks" % np.nanmean(fin - dry))

@@ -60,12 +60,13 @@ struct Tuning {
     int force_path;      // 0 auto, 1 plain kernel, 2 fused kernel
     int solve_waves;     // resident waves per SIMD of the fused kernel
     int refill_min;      // idle lanes that trigger a refill
+    unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
 };
 
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 3, 16};
+        Tuning v{0, 4, 16, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -288,6 +289,12 @@ int rtmi_set_option(const char *name, int value)
     return RTMI_OK;
 }
 
+int rtmi_debug_stamps(unsigned long long *d_stamps)
+{
+    tuning().d_stamps = d_stamps;
+    return RTMI_OK;
+}
+
 int rtmi_device_cus(void)
 {
     Context &c = ctx();
@@ -313,7 +320,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
     const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
     if (fused) {
         HIP_TRY(rtmi_launch_fused(d_vels, d_depths, nlayers, d_src_offset, d_src_depth, nsrc, d_timeP, d_p_final,
-                                  num_cus_for_current_device(), tn.solve_waves, tn.refill_min,
+                                  num_cus_for_current_device(), tn.solve_waves, tn.refill_min, tn.d_stamps,
                                   (hipStream_t)stream));
         return RTMI_OK;
     }
@@ -331,6 +338,17 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
     a.d_p_final = d_p_final;
     const int gx = rtmi_launch_grid_x(nsrc, 1, num_cus_for_current_device());
     HIP_TRY(rtmi_launch_trace(&a, 1, nlayers, gx, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                           unsigned long long *d_mismatch, void *stream)
+{
+    if (n < 0 || !d_w || !d_num || !d_den || !d_mismatch)
+        return fail(RTMI_ERR_BAD_ARG, "bad argument");
+    if (n == 0)
+        return RTMI_OK;
+    HIP_TRY(rtmi_launch_fastmath_check(d_w, d_num, d_den, n, d_mismatch, (hipStream_t)stream));
     return RTMI_OK;
 }
 

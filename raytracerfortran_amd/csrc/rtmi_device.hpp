@@ -21,7 +21,7 @@ enum : int {
 };
 
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of (nlayers + 1) doubles.
-#define RTMI_TABLE_ARRAYS 9
+#define RTMI_TABLE_ARRAYS 10
 struct LayerTable {
     double *D;     // D[i]    depth to interface i                       i < nlayers
     double *V;     // V[i]    velocity of layer i                        i <= nlayers
@@ -32,6 +32,7 @@ struct LayerTable {
     double *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
     double *VMI;   // VMI[i]  1/VMAX[i]                                  i <= nlayers
     double *Q;     // scratch H[i]/V[i]
+    double *HVOK;  // HVOK[i] 1.0 if HV[0..i] are all 0 or of moderate magnitude (fast-path guard), else 0.0
 };
 
 __device__ __forceinline__ LayerTable carve_table(double *lds, int nlayers)
@@ -47,7 +48,16 @@ __device__ __forceinline__ LayerTable carve_table(double *lds, int nlayers)
     t.VMAX = lds + 6 * n1;
     t.VMI = lds + 7 * n1;
     t.Q = lds + 8 * n1;
+    t.HVOK = lds + 9 * n1;
     return t;
+}
+
+// v == 0 or |v| inside (1e-30, 1e30): safe as one factor of a numerator of div_guarded (the product of two
+// such factors stays far from the exponent ranges where v_div_scale / v_div_fixup would act).
+__device__ __forceinline__ bool mag_ok(double v)
+{
+    const double a = fabs(v);
+    return v == 0.0 || (a > 1e-30 && a < 1e30);
 }
 
 // Derive the table of one model (whole workgroup; ends with a barrier).  Roundings are the reference's:
@@ -75,8 +85,10 @@ __device__ __forceinline__ void stage_model(const LayerTable &t, const double *_
     if (threadIdx.x == 0) {
         double s = t.Q[0];
         double m = t.V[0];
+        bool ok = mag_ok(t.HV[0]);
         t.PS[0] = s;
         t.VMAX[0] = m;
+        t.HVOK[0] = ok ? 1.0 : 0.0;
         for (int i = 1; i <= nlayers; ++i) {
             const double v = t.V[i];
             m = (v > m) ? v : m;  // maxval(): order-free
@@ -84,6 +96,8 @@ __device__ __forceinline__ void stage_model(const LayerTable &t, const double *_
             if (i < nlayers) {
                 s = s + t.Q[i];
                 t.PS[i] = s;
+                ok = ok && mag_ok(t.HV[i]);
+                t.HVOK[i] = ok ? 1.0 : 0.0;
             }
         }
     }
@@ -121,32 +135,102 @@ __device__ __forceinline__ int which_layer(const LayerTable &t, int nlayers, dou
     return nl;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Correctly rounded sqrt and divide without the range handling the general expansions carry.
+//
+// hipcc expands an fp64 `sqrt(w)` to  v_rsq_f64 + the Goldschmidt/Newton steps below, wrapped in a
+// pre/post scaling for w < 2^-767 and a class test for 0/inf, and an fp64 `n / d` to
+// v_div_scale x2 + v_rcp_f64 + the steps below + v_div_fmas + v_div_fixup, where the scale/fixup
+// instructions only act on operands or quotients near the ends of the exponent range (and on 0, inf,
+// NaN).  The fast forms are the SAME instruction sequences with those no-op wrappers removed, so for
+// operands inside the guarded ranges they return the same bits as `sqrt` and `/` (checked on the
+// GPU by tests/test_gpu_parity.py::test_fast_math_equals_ieee against the plain operators on the
+// operands of real solves and on random operands).  eval_f_fp only takes them when every operand
+// of the wave is inside the guard, and otherwise re-evaluates with the plain operators.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sqrt_guarded(double w)  // w in (1e-60, 1]
+{
+    const double y = __builtin_amdgcn_rsq(w);
+    double g = w * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, w);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, w);
+    g = __builtin_fma(d, h, g);
+    return g;
+}
+
+__device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-90, 1], n == 0 or |n| in (1e-60, 1e60)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    const double res = __builtin_fma(-d, q, n);
+    return __builtin_fma(res, r, q);
+}
+
 // costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
 // `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
-__device__ __forceinline__ void eval_f_fp(const LayerTable &t, double x, int nfull, int nfull_wave,
-                                          double hvl, double vvl, double R, double &f, double &fp)
+template <bool FAST>
+__device__ __forceinline__ bool eval_terms(const LayerTable &t, double x, int nfull, int nfull_wave, double hvl,
+                                           double vvl, double R, double &f, double &fp)
 {
     const double xx = x * x;
     double sf = 0.0, sp = 0.0;
+    bool ok = true;
     for (int i = 0; i < nfull_wave; ++i) {
         const double hv = t.HV[i];
         const double vv = t.VV[i];
-        const double s = sqrt(1.0 - xx * vv);
-        const double tf = (hv * x) / s;
-        const double tp = hv / ((s * s) * s);
+        const double w = 1.0 - xx * vv;
+        double tf, tp;
+        if (FAST) {
+            ok = ok && (w > 1e-60 || i >= nfull);
+            const double s = sqrt_guarded(w);
+            tf = div_guarded(hv * x, s);
+            tp = div_guarded(hv, (s * s) * s);
+        } else {
+            const double s = sqrt(w);
+            tf = (hv * x) / s;
+            tp = hv / ((s * s) * s);
+        }
         if (i < nfull) {
             sf = sf + tf;
             sp = sp + tp;
         }
     }
     {
-        const double s = sqrt(1.0 - xx * vvl);
-        sf = sf + (hvl * x) / s;
-        sp = sp + hvl / ((s * s) * s);
+        const double w = 1.0 - xx * vvl;
+        if (FAST) {
+            ok = ok && (w > 1e-60);
+            const double s = sqrt_guarded(w);
+            sf = sf + div_guarded(hvl * x, s);
+            sp = sp + div_guarded(hvl, (s * s) * s);
+        } else {
+            const double s = sqrt(w);
+            sf = sf + (hvl * x) / s;
+            sp = sp + hvl / ((s * s) * s);
+        }
     }
     f = R - sf;
     fp = -sp;
+    return ok;
+}
+
+// `numer_ok`: lane-constant part of the guard (table products and hvl are 0 or of moderate magnitude).
+// `busy`: the lane carries a live source (idle lanes never veto the fast path).
+__device__ __forceinline__ void eval_f_fp(const LayerTable &t, double x, int nfull, int nfull_wave, double hvl,
+                                          double vvl, double R, bool numer_ok, bool busy, double &f, double &fp)
+{
+    const bool ok = eval_terms<true>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
+    if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
+        eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
 }
 
 // Solver state of one source (one lane).
@@ -163,6 +247,7 @@ struct Lane {
     int st;
     int k;        // trip counter of the current loop
     bool conv;
+    bool numer_ok;  // hvl and the table products of the stack are inside eval_f_fp's fast-path guard
 };
 
 // The source's layer-dependent constants (InsertLayer :38-69 as table lookups).  il = nl - 1 >= 1.
@@ -175,6 +260,7 @@ __device__ __forceinline__ void lane_setup(Lane &s, const LayerTable &t, int il,
     s.vvl = t.VV[il];
     s.vmi = t.VMI[il];
     s.nfull = il;
+    s.numer_ok = mag_ok(s.hvl) && (t.HVOK[il - 1] != 0.0);
 }
 
 // GetPTime head (:112-133): the starting ray parameter.  Returns NaN when the reference would loop
@@ -212,88 +298,69 @@ __device__ __forceinline__ void lane_start(Lane &s, double p0)
 
 // One transition of the per-lane state machine after (f, f') was evaluated at s.xe.
 // GetPTime's three-way branch (:136-153), solvebst (:339-405) and solve (:226-332).
+//
+// Written as predicates + selects rather than one branch per state: the lanes of a wave are in
+// different states almost always, so a branchy dispatch executes every state's body on every trip;
+// the select form shares the common pieces (one quotient, one `check_x`, one Newton update).
+// Every value is computed by the same operation on the same operands as in the reference.
 __device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
 {
-    const double safe = s.vmi - 1e-10;  // 1/maxval(V)-(1d-10)      (:142, :388)
-    // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294) are the same quotient of the
-    // same two operands: divide once, ahead of the (lane-divergent) state dispatch.
+    const int st = s.st;
+    const bool isI = (st == ST_INIT), isB0 = (st == ST_BIS0), isB = (st == ST_BIS), isN = (st == ST_NEWTON),
+               isF = (st == ST_FINAL);
+    // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294): same operands, one divide
     const double q = f / fp;
-    bool newton_step = (s.st == ST_NEWTON);
-    if (s.st == ST_INIT) {
-        const double check_x = s.xe - q;
-        if (f < 0.0 || check_x < safe) {
-            s.st = ST_NEWTON;  // solve(p0): its first costFunc/costFunc_Prime pair is this one
-            s.k = 1;
-            s.x = s.xe;
-            newton_step = true;
-        } else {
-            s.st = ST_BIS0;  // solvebst(1d-10, 1/maxval(vp)-1d-12)
-            s.xe = 1e-10;
-        }
-    } else if (s.st == ST_BIS0) {
-        const double x1 = 1e-10, x2 = s.vmi - 1e-12;
-        if (f < 0.0) {
-            s.xb = x1;
-            s.dx = x2 - x1;
-        } else {
-            s.xb = x2;
-            s.dx = x1 - x2;
-        }
-        s.k = 1;
-        s.dx = s.dx * 0.5;
-        s.xe = s.xb + s.dx;
-        s.st = ST_BIS;
-    } else if (s.st == ST_BIS) {
-        // xe is xmid, f is fmid (== fx: the reference evaluates costFunc(xmid) twice), fp is fxprime
-        bool done = false;
-        if (f < 0.0)
-            s.xb = s.xe;
-        if (f == 0.0) {
-            done = true;
-        } else {
-            const double check_x = s.xb - q;
-            if (check_x < safe) {
-                s.xb = s.xe;
-                done = true;
-            } else if (fabs(f) < 0.1) {
-                done = true;
-            }
-        }
-        if (!done) {
-            if (s.k == 20) {
-                done = true;
-            } else {
-                ++s.k;
-                s.dx = s.dx * 0.5;
-                s.xe = s.xb + s.dx;
-            }
-        }
-        if (done) {
-            s.st = ST_NEWTON;  // p0 = p_final; call solve(p0, ...)   (:151-152)
-            s.k = 1;
-            s.x = s.xb;
-            s.xe = s.xb;
-        }
-    } else if (s.st == ST_FINAL) {
-        s.conv = fabs(f) > 0.1;  // the reference's inverted test (:327-330)
-        s.st = ST_DONE;
-    }
+    const bool neg = f < 0.0;
+    const bool small = fabs(f) < 0.1;   // abs(fx) < tol (:287), abs(fmid) < tol (:394)
+    const double safe = s.vmi - 1e-10;  // 1/maxval(V)-(1d-10)      (:142, :388)
 
-    if (newton_step) {
-        if (fabs(f) < 0.1) {
-            s.conv = true;
-            s.st = ST_DONE;
-        } else {
-            s.x = s.x - q;
-            if (s.x > s.vmi)
-                s.x = s.vmi - 1e-9;
-            s.xe = s.x;
-            if (s.k == 15)
-                s.st = ST_FINAL;
-            else
-                ++s.k;
-        }
-    }
+    // solvebst trip, first half: `if (fmid < 0) x = xmid` (:371-373)
+    const double xb1 = (isB && neg) ? s.xe : s.xb;
+    // check_x = p0 - cf/cfp (:138)  |  check_x = x - deltax (:386)
+    const double check_x = (isI ? s.xe : xb1) - q;
+    const bool jump = check_x < safe;
+
+    const bool initN = isI && (neg || jump);  // (:139-144) Newton straight from p0
+    const bool initB = isI && !initN;         // (:145-148) bisection first
+    const bool zero = (f == 0.0);
+    const bool bis_take = isB && !zero && jump;                                  // (:388-391) x = xmid; exit
+    const bool bis_done = isB && (zero || jump || small || s.k == 20);           // (:375, :388, :394, maxiter)
+    const bool bis_cont = isB && !bis_done;
+    const double xb2 = bis_take ? s.xe : xb1;
+
+    // solve trip (:269-311); for initN this evaluation is solve's first (x = p0)
+    const bool newt = isN || initN;
+    const double xN = initN ? s.xe : s.x;
+    const int kN = initN ? 1 : s.k;
+    const bool n_conv = newt && small;
+    const bool n_go = newt && !small;
+    double xnew = xN - q;                // x = x - deltax (:298)
+    if (xnew > s.vmi)
+        xnew = s.vmi - 1e-9;             // (:299-304)
+
+    // solvebst entry (:354-365): x1 = 1d-10, x2 = 1/maxval(vp)-1d-12
+    const double x2 = s.vmi - 1e-12;
+    const double d21 = x2 - 1e-10;
+    const double xb0 = neg ? 1e-10 : x2;
+    const double dx0 = neg ? d21 : -d21;  // x2-x1 | x1-x2 (exact negation)
+    // dx = dx*0.5; xmid = x + dx (:368-369) for the first and for every further trip
+    const bool halve = isB0 || bis_cont;
+    const double dxh = (isB0 ? dx0 : s.dx) * 0.5;
+    const double xbh = isB0 ? xb0 : xb2;
+    const double xmid = xbh + dxh;
+
+    // ---- commit -----------------------------------------------------------------------------
+    s.xb = isB0 ? xb0 : (isB ? xb2 : s.xb);
+    s.dx = halve ? dxh : s.dx;
+    s.x = n_go ? xnew : (n_conv ? xN : (bis_done ? xb2 : s.x));
+    s.xe = initB ? 1e-10 : (halve ? xmid : (bis_done ? xb2 : (n_go ? xnew : s.xe)));
+    s.k = isB0 ? 1 : (bis_cont ? s.k + 1 : (bis_done ? 1 : ((n_go && kN != 15) ? kN + 1 : (initN ? 1 : s.k))));
+    s.conv = n_conv ? true : (isF ? (fabs(f) > 0.1) : s.conv);  // (:288) | the inverted test (:327-330)
+    s.st = initB ? ST_BIS0
+                 : (isB0 || bis_cont) ? ST_BIS
+                                      : bis_done ? ST_NEWTON
+                                                 : n_go ? (kN == 15 ? ST_FINAL : ST_NEWTON)
+                                                        : (n_conv || isF) ? ST_DONE : st;
 }
 
 // Travel time for a known ray parameter (:156, :165-166).  Wave-uniform loop.

@@ -7,6 +7,7 @@
 
 #define RTMI_BLOCK 256          // threads per workgroup (4 waves: one per SIMD of a CU)
 #define RTMI_BLOCKS_PER_CU 16   // grid cap = CUs x this; further tiles are grid-strided
+#define RTMI_STAMPS_PER_WG 36  // diagnostic clocks per workgroup: 4 phase stamps + 2 per wave
 #define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
 
 namespace rtmi {
@@ -40,6 +41,7 @@ struct FusedArgs {
     int64_t nsrc;
     double *d_timeP;
     double *d_p_final;           // or NULL
+    unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
 };
 
 }  // namespace rtmi
@@ -49,7 +51,10 @@ int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_si
                         size_t *lds_bytes);
 hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
                              const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final,
-                             int num_cus, int waves_per_simd, int refill_min, hipStream_t stream);
+                             int num_cus, int waves_per_simd, int refill_min, unsigned long long *d_stamps,
+                             hipStream_t stream);
+hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                                      unsigned long long *d_out, hipStream_t stream);
 int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);
 hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
                              hipStream_t stream);

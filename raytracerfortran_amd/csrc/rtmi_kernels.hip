@@ -65,7 +65,7 @@ __device__ __forceinline__ double trace_one(const LayerTable &t, int nlayers, do
 
     while (__any(s.st != ST_DONE)) {
         double f, fp;
-        eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
+        eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, s.st != ST_DONE, f, fp);
         lane_advance(s, f, fp);
     }
 
@@ -187,8 +187,13 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
     const int CH = slots / 64;
     const int nl_max = a.nlayers + 1;
 
+    // Diagnostic phase clocks (NULL in normal runs): per workgroup {start, after sort, after solve, after time}
+    // of its FIRST round, in shader-clock ticks.  The stamps go to a buffer nothing else reads.
+    unsigned long long *stamps = a.d_stamps ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
     for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
         // ---- a. load + workgroup-local counting sort -------------------------------------------
+        if (stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[0] = clock64();
         if (threadIdx.x < 64)
             hist[threadIdx.x] = 0;
         __syncthreads();
@@ -249,6 +254,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
         }
         __syncthreads();
         const int nq = (int)qctl[1];
+        if (stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[1] = clock64();
 
         // ---- b. solve: every wave pulls from the workgroup's queue, lanes refill as they finish ----
         Lane s;
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
         s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = 0.0;
         s.k = 0;
         s.conv = false;
+        s.numer_ok = true;
         int slot = 0;
         bool exhausted = false;  // wave-uniform: the queue head has passed nq
         int nfull_wave = 0;
@@ -269,6 +277,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                     base = atomicAdd(&qctl[0], (uint32_t)nidle);
                 base = __shfl(base, 0, 64);
                 exhausted = (int)base + nidle >= nq;
+                if (stamps && j0 == 0 && exhausted && lane == 0)
+                    stamps[4 + 2 * wib] = clock64();  // this wave saw the queue run dry
                 if (s.st == ST_DONE) {
                     const int q = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
                     if (q < nq) {
@@ -284,13 +294,16 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
             }
             if (__all(s.st == ST_DONE)) {
-                if (exhausted)
+                if (exhausted) {
+                    if (stamps && j0 == 0 && lane == 0)
+                        stamps[5 + 2 * wib] = clock64();  // this wave's last source finished
                     break;
+                }
                 continue;  // all 64 lanes idle: the next trip refills
             }
             double f, fp;
-            eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, f, fp);
             const bool was_busy = (s.st != ST_DONE);
+            eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
             lane_advance(s, f, fp);
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
@@ -299,6 +312,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             }
         }
         __syncthreads();
+        if (stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[2] = clock64();
 
         // ---- c. travel times in sorted order ----------------------------------------------------
         for (int q0 = wib * 64; q0 < nq; q0 += nwib * 64) {
@@ -321,7 +336,29 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             }
         }
         __syncthreads();
+        if (stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[3] = clock64();
     }
+}
+
+// Diagnostic: bitwise comparison of the guarded sqrt/divide with the plain operators.
+// out[0] += sqrt mismatches over w[], out[1] += divide mismatches over (num[], den[]).
+__global__ void fastmath_check_kernel(const double *__restrict__ w, const double *__restrict__ num,
+                                      const double *__restrict__ den, int64_t n, unsigned long long *out)
+{
+    unsigned long long bad_s = 0, bad_d = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = sqrt_guarded(w[i]);
+        const double b = sqrt(w[i]);
+        bad_s += (__double_as_longlong(a) != __double_as_longlong(b));
+        const double c = div_guarded(num[i], den[i]);
+        const double d = num[i] / den[i];
+        bad_d += (__double_as_longlong(c) != __double_as_longlong(d));
+    }
+    if (bad_s)
+        atomicAdd(&out[0], bad_s);
+    if (bad_d)
+        atomicAdd(&out[1], bad_d);
 }
 
 }  // namespace rtmi
@@ -416,7 +453,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int w
 extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers,
                                         const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                                         double *d_timeP, double *d_p_final, int num_cus, int waves_per_simd,
-                                        int refill_min, hipStream_t stream)
+                                        int refill_min, unsigned long long *d_stamps, hipStream_t stream)
 {
     using namespace rtmi;
     static bool attr_set = false;
@@ -441,6 +478,7 @@ extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_de
     a.nsrc = nsrc;
     a.d_timeP = d_timeP;
     a.d_p_final = d_p_final;
+    a.d_stamps = d_stamps;
     size_t lds_bytes = 0;
     int threads = 0;
     const int nblocks = rtmi_fused_geometry(nsrc, nlayers, num_cus, waves_per_simd, &threads, &a.slots, &lds_bytes);
@@ -451,5 +489,12 @@ extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_de
         hipLaunchKernelGGL((fused_kernel<true>), grid, block, lds_bytes, stream, a);
     else
         hipLaunchKernelGGL((fused_kernel<false>), grid, block, lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den,
+                                                 int64_t n, unsigned long long *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rtmi::fastmath_check_kernel, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, d_out);
     return hipGetLastError();
 }

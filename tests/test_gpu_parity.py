@@ -222,7 +222,7 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
         t3 = rt.trace_device(dv, dd, do, dz).cpu().numpy()  # without p_final
     finally:
         rt.set_option("path", 0)
-        rt.set_option("waves_per_simd", 3)
+        rt.set_option("waves_per_simd", 4)
         rt.set_option("refill_min", 16)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
@@ -231,6 +231,40 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
     good = (nl > 1) & np.isfinite(off) & np.isfinite(dep)
     assert np.array_equal(p2[good], pref[good]) and np.all(np.isnan(p2[nl == 1]))
     assert np.array_equal(p1[good], p2[good])
+
+
+def test_fast_math_equals_ieee(rt):
+    """The guarded sqrt / divide (compiler expansions without their exponent-range wrappers) return the same
+    bits as the plain operators over the guarded operand ranges: random operands, operands shaped like the
+    solver's (w = 1 - p^2 v^2 near 0 and near 1), and the guard's boundary decades."""
+    import torch
+    from raytracerfortran_amd import raymod
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = 1 << 24
+    total_s = total_d = 0
+    for trial in range(4):
+        u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        e = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        if trial == 0:      # solver-like: w in (0, 1], numerators ~ H*V*p, denominators s and s^3
+            w = 1.0 - u * u * (1.0 - 1e-12)
+            den = torch.sqrt(w) ** (1 + 2 * (e > 0.5))
+            num = (u + 0.1) * 1e4 * torch.exp(-20 * e)
+        elif trial == 1:    # near-critical: w tiny
+            w = torch.exp(-100.0 * u) * (1.0 - 1e-16) + 1e-59
+            den = torch.exp(-190.0 * e) + 1e-89
+            num = torch.exp(138.0 * (u - 0.5)) * torch.sign(e - 0.3)
+        elif trial == 2:    # whole guarded range, log-uniform
+            w = torch.exp(-138.0 * u)
+            den = torch.exp(-207.0 * e)
+            num = torch.exp(276.0 * (u - 0.5))
+        else:               # exact zeros and ones among ordinary values
+            w = torch.where(u < 0.1, torch.ones_like(u), u)
+            den = torch.where(e < 0.1, torch.ones_like(e), e + 1e-3)
+            num = torch.where(u > 0.9, torch.zeros_like(u), u - 0.5)
+        bs, bd = raymod.selftest_fastmath(w.contiguous(), num.contiguous(), den.contiguous())
+        total_s += bs
+        total_d += bd
+    assert (total_s, total_d) == (0, 0)
 
 
 def test_fused_kernel_many_layers_and_host_path(rt, O):
@@ -255,7 +289,7 @@ def test_fused_kernel_several_rounds(rt, O):
         t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
                             torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
     finally:
-        rt.set_option("waves_per_simd", 3)
+        rt.set_option("waves_per_simd", 4)
     assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
 
 
