@@ -86,7 +86,7 @@ int rtmi_device_cus(void);
 /*
  * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
  *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel
- *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
+ *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 3)
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
  * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN.
  */

@@ -66,7 +66,7 @@ struct Tuning {
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, nullptr};
+        Tuning v{0, 3, 16, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -319,8 +319,19 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
     const Tuning tn = tuning();
     const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
     if (fused) {
-        HIP_TRY(rtmi_launch_fused(d_vels, d_depths, nlayers, d_src_offset, d_src_depth, nsrc, d_timeP, d_p_final,
-                                  num_cus_for_current_device(), tn.solve_waves, tn.refill_min, tn.d_stamps,
+        rtmi::FusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.d_vels = d_vels;
+        fa.d_depths = d_depths;
+        fa.nlayers = nlayers;
+        fa.refill_min = tn.refill_min;
+        fa.d_src_offset = d_src_offset;
+        fa.d_src_depth = d_src_depth;
+        fa.nsrc = nsrc;
+        fa.d_timeP = d_timeP;
+        fa.d_p_final = d_p_final;
+        fa.d_stamps = tn.d_stamps;
+        HIP_TRY(rtmi_launch_fused(&fa, 1, nlayers, num_cus_for_current_device(), tn.solve_waves, nullptr,
                                   (hipStream_t)stream));
         return RTMI_OK;
     }
@@ -356,7 +367,11 @@ int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc)
 {
     if (nmodels < 1 || nsrc < 0)
         return 0;
-    const int gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
+    // enough for either kernel's per-workgroup partial sums
+    const int cus = num_cus_for_current_device();
+    int64_t gx = rtmi_launch_grid_x(nsrc, nmodels, cus);
+    if (gx < 2 * cus)
+        gx = 2 * cus;
     return (int64_t)nmodels * gx * (int64_t)sizeof(double);
 }
 
@@ -394,8 +409,29 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
     a.d_p_final = nullptr;
     a.d_obs = want_ll ? d_obs : nullptr;
     a.d_partial = (double *)d_work;
-    const int gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
-    HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, (hipStream_t)stream));
+    const Tuning tn = tuning();
+    int gx = 0;
+    const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2);
+    if (fused) {
+        rtmi::FusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.d_vels = d_vels;
+        fa.d_depths = d_depths;
+        fa.d_nlayers = d_nlayers;
+        fa.ld_model = ld_model;
+        fa.refill_min = tn.refill_min;
+        fa.d_src_offset = d_src_offset;
+        fa.d_src_depth = d_src_depth;
+        fa.nsrc = nsrc;
+        fa.d_timeP = d_timeP;
+        fa.d_obs = want_ll ? d_obs : nullptr;
+        fa.d_partial = (double *)d_work;
+        HIP_TRY(rtmi_launch_fused(&fa, nmodels, ld_model - 1, num_cus_for_current_device(), tn.solve_waves, &gx,
+                                  (hipStream_t)stream));
+    } else {
+        gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
+        HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, (hipStream_t)stream));
+    }
     if (want_ll)
         HIP_TRY(rtmi_launch_loglike((const double *)d_work, gx, d_sd, nsrc, nmodels, d_logL, (hipStream_t)stream));
     return RTMI_OK;

@@ -28,31 +28,33 @@ struct TraceArgs {
     double *d_partial;    // [nmodels][grid_x] per-workgroup sums of squared residuals
 };
 
-// Arguments of the fused large-NSrc kernel (one model).
-#define RTMI_SLOT_BYTES 32  // LDS per queued record: offset, depth, p (f64) + key, nl scratch (u32)
+// Arguments of the fused large-NSrc kernel.  Model m = blockIdx.y uses row m of d_vels / d_depths.
+#define RTMI_SLOT_BYTES 34  // LDS per queued record: offset, depth, p (f64) + key, nl scratch (u32) + order (u16)
 struct FusedArgs {
-    const double *d_vels;
-    const double *d_depths;
+    const double *d_vels;        // [nmodels][ld_model]
+    const double *d_depths;      // [nmodels][ld_model]
+    const int32_t *d_nlayers;    // [nmodels] or NULL -> `nlayers` for every model
     int nlayers;
+    int ld_model;
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
-    const double *d_src_offset;
-    const double *d_src_depth;
+    const double *d_src_offset;  // [nsrc]
+    const double *d_src_depth;   // [nsrc]
     int64_t nsrc;
-    double *d_timeP;
-    double *d_p_final;           // or NULL
+    double *d_timeP;             // [nmodels][nsrc] or NULL
+    double *d_p_final;           // [nsrc] or NULL (single model only)
+    const double *d_obs;         // [nsrc] or NULL
+    double *d_partial;           // [nmodels][grid.x] per-workgroup sums of squared residuals
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
 };
 
 }  // namespace rtmi
 
 extern "C" {
-int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *threads, int *slots,
-                        size_t *lds_bytes);
-hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers, const double *d_src_offset,
-                             const double *d_src_depth, int64_t nsrc, double *d_timeP, double *d_p_final,
-                             int num_cus, int waves_per_simd, int refill_min, unsigned long long *d_stamps,
-                             hipStream_t stream);
+int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd, int *threads,
+                        int *slots, size_t *lds_bytes);
+hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
+                             int waves_per_simd, int *grid_x_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,
                                       unsigned long long *d_out, hipStream_t stream);
 int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);

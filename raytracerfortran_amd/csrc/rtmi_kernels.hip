@@ -159,15 +159,25 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..28
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
+#define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
-template <bool WANT_P>
+// grid.y = model (many models over one shared source set: loglhood.f90:128-146 per proposal); every
+// workgroup row b of a model owns chunks b, b + gridDim.x, ... of the sources.
+template <bool WANT_P, bool WANT_T, bool WANT_SS>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a)
 {
     extern __shared__ double lds[];
+    const int m = blockIdx.y;
+    a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
+    a.d_vels += (int64_t)m * a.ld_model;
+    a.d_depths += (int64_t)m * a.ld_model;
+    if (WANT_T)
+        a.d_timeP += (int64_t)m * a.nsrc;
     const LayerTable t = carve_table(lds, a.nlayers);
     stage_model(t, a.d_vels, a.d_depths, a.nlayers);
+    double ss = 0.0;  // this thread's sum of squared residuals (fused logL)
 
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
@@ -178,8 +188,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
     double *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
     uint32_t *tnl = rk + slots;                               // nl per local index (between the sort passes)
-    uint32_t *hist = tnl + slots;                             // 64 bins
-    uint32_t *qctl = hist + 64;                               // [0] queue head, [1] records queued
+    uint32_t *hist = tnl + slots;                             // [16 waves][64 bins] counts, then first slots
+    uint32_t *qctl = hist + 16 * 64;                          // [0] queue head, [1] records sorted, [2] long, [3] short
+    uint16_t *order = reinterpret_cast<uint16_t *>(qctl + 4); // solve order: slots of the long class, then the short
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -191,12 +202,14 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
     // of its FIRST round, in shader-clock ticks.  The stamps go to a buffer nothing else reads.
     unsigned long long *stamps = a.d_stamps ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
     for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
-        // ---- a. load + workgroup-local counting sort -------------------------------------------
+        // ---- a. load + workgroup-local STABLE counting sort ------------------------------------
+        // No atomics: lane b of each wave counts the wave's records of bin b in a register (one
+        // ballot per distinct bin of a chunk), so slots -- and with them the summation order of the
+        // fused logL -- are the same on every run.
         if (stamps && j0 == 0 && threadIdx.x == 0)
             stamps[0] = clock64();
-        if (threadIdx.x < 64)
-            hist[threadIdx.x] = 0;
-        __syncthreads();
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        uint32_t mycnt = 0;
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
@@ -208,12 +221,23 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
             tnl[c * 64 + lane] = (uint32_t)nl;
-            if (nl > 1)
-                atomicAdd(&hist[bin_of(nl, nl_max)], 1u);
+            const int bin = bin_of(nl, nl_max);
+            unsigned long long todo = __ballot(nl > 1);
+            while (todo) {
+                const int lb = __shfl(bin, __ffsll((long long)todo) - 1, 64);
+                const unsigned long long grp = __ballot(nl > 1 && bin == lb);
+                if (lane == lb)
+                    mycnt += (uint32_t)__popcll(grp);
+                todo &= ~grp;
+            }
         }
+        hist[wib * 64 + lane] = mycnt;
         __syncthreads();
         if (wib == 0) {
-            uint32_t incl = hist[lane];
+            uint32_t tot = 0;
+            for (int w = 0; w < nwib; ++w)
+                tot += hist[w * 64 + lane];
+            uint32_t incl = tot;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t o = __shfl_up(incl, off, 64);
@@ -221,39 +245,110 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                     incl += o;
             }
             const uint32_t total = __shfl(incl, 63, 64);
-            hist[lane] = total - incl;  // first slot of bin `lane` when bins are laid out descending
+            uint32_t run = total - incl;  // first slot of bin `lane` when bins are laid out descending
+            for (int w = 0; w < nwib; ++w) {
+                const uint32_t c = hist[w * 64 + lane];
+                hist[w * 64 + lane] = run;  // first slot of (wave w, bin lane)
+                run += c;
+            }
             if (lane == 0) {
                 qctl[0] = 0;
                 qctl[1] = total;
+                qctl[2] = 0;
+                qctl[3] = 0;
             }
         }
         __syncthreads();
+        uint32_t woff = hist[wib * 64 + lane];  // lane b: next free slot of bin b for this wave
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
-            if (k < a.nsrc) {
-                const int nl = (int)tnl[c * 64 + lane];
+            const bool valid = k < a.nsrc;
+            const int nl = valid ? (int)tnl[c * 64 + lane] : 1;
+            const int bin = bin_of(nl, nl_max);
+            uint32_t pos = 0;
+            unsigned long long todo = __ballot(nl > 1);
+            while (todo) {
+                const int lb = __shfl(bin, __ffsll((long long)todo) - 1, 64);
+                const unsigned long long grp = __ballot(nl > 1 && bin == lb);
+                const uint32_t start = __shfl(woff, lb, 64);
+                if (nl > 1 && bin == lb)
+                    pos = start + (uint32_t)__popcll(grp & lt_mask);
+                if (lane == lb)
+                    woff += (uint32_t)__popcll(grp);
+                todo &= ~grp;
+            }
+            if (valid) {
                 const double R = a.d_src_offset[k];
                 const double z = a.d_src_depth[k];
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
-                    a.d_timeP[k] = sqrt(z * z + R * R) / t.V[0];
+                    const double tt = sqrt(z * z + R * R) / t.V[0];
+                    if (WANT_T)
+                        a.d_timeP[k] = tt;
                     if (WANT_P)
                         a.d_p_final[k] = __builtin_nan("");
+                    if (WANT_SS) {
+                        const double r = a.d_obs[k] - tt;
+                        ss = ss + r * r;
+                    }
                 } else {
-                    const double p0 = initial_p0(t, nl - 1, R, z);
-                    const uint32_t pos = atomicAdd(&hist[bin_of(nl, nl_max)], 1u);
                     rR[pos] = R;
                     rz[pos] = z;
-                    rp[pos] = p0;
+                    rp[pos] = initial_p0(t, nl - 1, R, z);
                     rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
                 }
             }
         }
         __syncthreads();
         const int nq = (int)qctl[1];
+
+        // ---- a2. first evaluation of every record, in sorted order (one layer count per wave) -------
+        // GetPTime's branch (:136-153) is taken here, at full lane occupancy.  It also tells which
+        // sources are long (bisection first: 2 + up to 20 + up to 16 further evaluations) and which are
+        // short (Newton from p0, typically 2-3 more): the solve queue takes the long class first, so
+        // that the drain at the end of the round -- when lanes can no longer be refilled -- is made of
+        // short sources.  Sources that converge at p0 are finished here.
+        for (int q0 = wib * 64; q0 < nq; q0 += nwib * 64) {
+            const int q = q0 + lane;
+            const bool valid = q < nq;
+            Lane s;
+            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+            const double p0 = valid ? rp[q] : 0.0;
+            lane_setup(s, t, nl - 1, valid ? rR[q] : 1.0, valid ? rz[q] : 1.0);
+            lane_start(s, p0);
+            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
+            if (!live)
+                s.st = ST_DONE;
+            const int nfw = wave_max_i32(live ? s.nfull : 0);
+            double f, fp;
+            eval_f_fp(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            if (live)
+                lane_advance(s, f, fp);
+            if (valid) {
+                uint32_t k2 = key;
+                if (s.st == ST_DONE) {
+                    rp[q] = s.x;
+                    if (s.conv)
+                        k2 |= RTMI_RK_CONV;
+                } else {
+                    rp[q] = s.xe;  // BIS0: 1e-10; NEWTON: the first Newton iterate (x == xe)
+                    const bool is_long = (s.st == ST_BIS0);
+                    if (!is_long)
+                        k2 |= RTMI_RK_SHORT;
+                    // long class fills order[] from the front, short class from the back
+                    const uint32_t pos = is_long ? atomicAdd(&qctl[2], 1u) : (uint32_t)(nq - 1) - atomicAdd(&qctl[3], 1u);
+                    order[pos] = (uint16_t)q;
+                }
+                rk[q] = k2;
+            }
+        }
+        __syncthreads();
+        const int n_long = (int)qctl[2];
+        const int n_todo = n_long + (int)qctl[3];  // records that need the solve loop
         if (stamps && j0 == 0 && threadIdx.x == 0)
             stamps[1] = clock64();
 
@@ -266,7 +361,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
         s.conv = false;
         s.numer_ok = true;
         int slot = 0;
-        bool exhausted = false;  // wave-uniform: the queue head has passed nq
+        bool exhausted = false;  // wave-uniform: the queue head has passed n_todo
         int nfull_wave = 0;
         for (;;) {
             const unsigned long long idle = __ballot(s.st == ST_DONE);
@@ -276,18 +371,24 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 if (lane == 0)
                     base = atomicAdd(&qctl[0], (uint32_t)nidle);
                 base = __shfl(base, 0, 64);
-                exhausted = (int)base + nidle >= nq;
+                exhausted = (int)base + nidle >= n_todo;
                 if (stamps && j0 == 0 && exhausted && lane == 0)
                     stamps[4 + 2 * wib] = clock64();  // this wave saw the queue run dry
                 if (s.st == ST_DONE) {
-                    const int q = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
-                    if (q < nq) {
-                        const double p0 = rp[q];
-                        if (p0 == p0) {  // NaN p0: the reference never returns; stays unconverged -> -999
-                            const int nl = (int)((rk[q] >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
-                            slot = q;
-                            lane_setup(s, t, nl - 1, rR[q], rz[q]);
-                            lane_start(s, p0);
+                    const int qi = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (qi < n_todo) {
+                        // long class front to back, then the short class from the top of order[] downwards:
+                        // both in descending layer order
+                        slot = (int)order[qi < n_long ? qi : (nq - 1) - (qi - n_long)];
+                        const uint32_t key = rk[slot];
+                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                        lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
+                        lane_start(s, rp[slot]);
+                        if (key & RTMI_RK_SHORT) {
+                            s.st = ST_NEWTON;  // solve(p0) after its first iteration
+                            s.k = 2;
+                        } else {
+                            s.st = ST_BIS0;    // solvebst(1d-10, ...): rp holds x1 = 1e-10
                         }
                     }
                 }
@@ -330,14 +431,36 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             if (valid) {
                 const int loc = (int)(key & RTMI_RK_LOC_MASK);
                 const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
-                a.d_timeP[k] = tt;
+                if (WANT_T)
+                    a.d_timeP[k] = tt;
                 if (WANT_P)
                     a.d_p_final[k] = p;
+                if (WANT_SS) {
+                    const double r = a.d_obs[k] - tt;
+                    ss = ss + r * r;
+                }
             }
         }
         __syncthreads();
         if (stamps && j0 == 0 && threadIdx.x == 0)
             stamps[3] = clock64();
+    }
+
+    if (WANT_SS) {
+        // workgroup reduction in a fixed order: lanes by xor-butterfly, then waves 0..nwib-1
+        double *wsum = rR;  // the record area is free now (the round loop ended with a barrier)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            ss = ss + __shfl_xor(ss, off, 64);
+        if (lane == 0)
+            wsum[wib] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = wsum[0];
+            for (int w = 1; w < nwib; ++w)
+                tot = tot + wsum[w];
+            a.d_partial[(int64_t)m * gridDim.x + blockIdx.x] = tot;
+        }
     }
 }
 
@@ -414,20 +537,23 @@ extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, c
 }
 
 // Geometry of the fused kernel: one workgroup of 64 x `waves_per_simd` x 4 threads per CU (two for more than 4
-// waves per SIMD), holding as many of its records in LDS as its share of the CU's 160 KiB allows.
-// Returns workgroups; *threads per workgroup, *slots = records per workgroup and round (multiple of 64),
-// *lds_bytes per workgroup.
-extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int waves_per_simd, int *threads,
-                                   int *slots, size_t *lds_bytes)
+// waves per SIMD), holding as many of its records in LDS as its share of the CU's 160 KiB allows.  With several
+// models the CUs are divided among them (grid.y = model).  Returns workgroups PER MODEL; *threads per workgroup,
+// *slots = records per workgroup and round (multiple of 64), *lds_bytes per workgroup (table sized for
+// `max_nlayers`).
+extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd,
+                                   int *threads, int *slots, size_t *lds_bytes)
 {
     const int64_t nchunks = (nsrc + 63) / 64;
     if (waves_per_simd < 1)
         waves_per_simd = 1;
     if (waves_per_simd > 8)
         waves_per_simd = 8;
+    if (nmodels < 1)
+        nmodels = 1;
     const int wg_per_cu = waves_per_simd > 4 ? 2 : 1;
     int waves = 4 * ((waves_per_simd + wg_per_cu - 1) / wg_per_cu);  // waves per workgroup, <= 16
-    int64_t nblocks = (int64_t)num_cus * wg_per_cu;
+    int64_t nblocks = ((int64_t)num_cus * wg_per_cu) / nmodels;        // per model
     if (nblocks > nchunks)
         nblocks = nchunks;
     if (nblocks < 1)
@@ -435,8 +561,8 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int w
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (nlayers + 1) * sizeof(double);
-    const size_t fixed = table + 66 * sizeof(uint32_t) + 8;
+    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(double);
+    const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 8;
     size_t share = (size_t)160 * 1024 / wg_per_cu;
     int64_t max_slots = share > fixed + 64 * RTMI_SLOT_BYTES ? (int64_t)((share - fixed) / RTMI_SLOT_BYTES / 64 * 64) : 64;
     if (max_slots > 8128)
@@ -450,45 +576,55 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int nlayers, int num_cus, int w
     return (int)nblocks;
 }
 
-extern "C" hipError_t rtmi_launch_fused(const double *d_vels, const double *d_depths, int nlayers,
-                                        const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
-                                        double *d_timeP, double *d_p_final, int num_cus, int waves_per_simd,
-                                        int refill_min, unsigned long long *d_stamps, hipStream_t stream)
+template <bool P, bool T, bool S>
+static hipError_t set_fused_lds_limit()
+{
+    // dynamic LDS above 64 KiB needs the opt-in
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<P, T, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// args: d_vels/d_depths/(d_nlayers|nlayers)/ld_model, sources, outputs, refill_min, d_stamps filled by the
+// caller; slots is set here.  *grid_x_out (may be NULL) receives the workgroups per model (= partial sums per model).
+extern "C" hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
+                                        int waves_per_simd, int *grid_x_out, hipStream_t stream)
 {
     using namespace rtmi;
     static bool attr_set = false;
     if (!attr_set) {
-        // dynamic LDS above 64 KiB needs the opt-in (large layer tables)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = set_fused_lds_limit<false, true, false>();
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = set_fused_lds_limit<true, true, false>();
+        if (e == hipSuccess)
+            e = set_fused_lds_limit<false, true, true>();
+        if (e == hipSuccess)
+            e = set_fused_lds_limit<false, false, true>();
         if (e != hipSuccess)
             return e;
         attr_set = true;
     }
-    FusedArgs a;
-    a.d_vels = d_vels;
-    a.d_depths = d_depths;
-    a.nlayers = nlayers;
-    a.refill_min = refill_min < 1 ? 1 : (refill_min > 64 ? 64 : refill_min);
-    a.d_src_offset = d_src_offset;
-    a.d_src_depth = d_src_depth;
-    a.nsrc = nsrc;
-    a.d_timeP = d_timeP;
-    a.d_p_final = d_p_final;
-    a.d_stamps = d_stamps;
+    FusedArgs a = *args;
+    a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
-    const int nblocks = rtmi_fused_geometry(nsrc, nlayers, num_cus, waves_per_simd, &threads, &a.slots, &lds_bytes);
+    const int nblocks =
+        rtmi_fused_geometry(a.nsrc, max_nlayers, nmodels, num_cus, waves_per_simd, &threads, &a.slots, &lds_bytes);
+    if (grid_x_out)
+        *grid_x_out = nblocks;
     if (lds_bytes > 160 * 1024)
         return hipErrorInvalidValue;
-    const dim3 grid(nblocks, 1, 1), block(threads, 1, 1);
-    if (d_p_final)
-        hipLaunchKernelGGL((fused_kernel<true>), grid, block, lds_bytes, stream, a);
+    const dim3 grid(nblocks, nmodels, 1), block(threads, 1, 1);
+    const bool want_p = a.d_p_final != nullptr;
+    const bool want_t = a.d_timeP != nullptr;
+    const bool want_ss = a.d_obs != nullptr;
+    if (want_ss && want_t)
+        hipLaunchKernelGGL((fused_kernel<false, true, true>), grid, block, lds_bytes, stream, a);
+    else if (want_ss)
+        hipLaunchKernelGGL((fused_kernel<false, false, true>), grid, block, lds_bytes, stream, a);
+    else if (want_p)
+        hipLaunchKernelGGL((fused_kernel<true, true, false>), grid, block, lds_bytes, stream, a);
     else
-        hipLaunchKernelGGL((fused_kernel<false>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((fused_kernel<false, true, false>), grid, block, lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -222,7 +222,7 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
         t3 = rt.trace_device(dv, dd, do, dz).cpu().numpy()  # without p_final
     finally:
         rt.set_option("path", 0)
-        rt.set_option("waves_per_simd", 4)
+        rt.set_option("waves_per_simd", 3)
         rt.set_option("refill_min", 16)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
@@ -289,7 +289,7 @@ def test_fused_kernel_several_rounds(rt, O):
         t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
                             torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
     finally:
-        rt.set_option("waves_per_simd", 4)
+        rt.set_option("waves_per_simd", 3)
     assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
 
 
@@ -328,6 +328,41 @@ def test_trace_batch_device_and_loglike(rt, O):
         assert compare_times(T[m], ref, TOL) == 0.0
         ll = O.oracle_loglhood_rt(obs, ref, sd[m], stable=True)
         assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_batch_paths_agree_c3_shape(rt, O, path):
+    """BASELINE config 3 shape: 32 models (k = 2..10) over 1e4 shared sources, travel times and fused logL,
+    through the plain kernel (path 1) and the fused kernel (path 2)."""
+    import torch
+    rng = np.random.default_rng(3)
+    nm, n, ld = 32, 10000, 16
+    x, y = rng.uniform(10, 6500, n), rng.uniform(10, 4500, n)
+    off, dep = np.sqrt(x * x + y * y), rng.uniform(1050, 4200, n)
+    V, D, NL = np.zeros((nm, ld)), np.zeros((nm, ld)), np.zeros(nm, np.int32)
+    for m in range(nm):
+        k = int(rng.integers(2, 11))
+        D[m, :k - 1] = np.sort(rng.uniform(100.1, 10000.1, k - 1))
+        V[m, :k] = rng.uniform(1500, 10000, k)
+        NL[m] = k - 1
+    sd = rng.uniform(0.001, 0.07, nm)
+    obs = O.oracle_dff(V[0, :NL[0] + 1], D[0, :NL[0]], off, dep) + rng.normal(0, 0.016, n)
+    dev = "cuda"
+    args = [torch.tensor(a, device=dev) for a in (V, D, NL, off, dep)]
+    try:
+        rt.set_option("path", path)
+        T, L = rt.trace_batch_device(*args, obs=torch.tensor(obs, device=dev), sd=torch.tensor(sd, device=dev))
+        _, L2 = rt.trace_batch_device(*args, obs=torch.tensor(obs, device=dev), sd=torch.tensor(sd, device=dev),
+                                      want_timeP=False)
+    finally:
+        rt.set_option("path", 0)
+    T, L, L2 = T.cpu().numpy(), L.cpu().numpy(), L2.cpu().numpy()
+    assert np.array_equal(L, L2)
+    for m in range(nm):
+        ref = O.oracle_dff(V[m, :NL[m] + 1], D[m, :NL[m]], off, dep)
+        assert compare_times(T[m], ref, TOL) == 0.0
+        ll = O.oracle_loglhood_rt(obs, ref, sd[m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll)
 
 
 def test_loglike_test_1_map(rt, kat):
