@@ -163,6 +163,61 @@ def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None,
     return elapsed, (kern_ms if kern_ms >= 0 else None)
 
 
+def bench_pt(args, rt, torch, dist, rank, world, dev):
+    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py): 32 chains per GPU over 1e4 shared sources
+    (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
+    logL all-gather over RCCL.  A "step" is one sweep of every chain; value = travel times traced per second."""
+    from raytracerfortran_amd import tempering as T
+    nsrc = 10_000 if args.nsrc == 1_000_000 else args.nsrc
+    rng = np.random.default_rng(2024)
+    x, y = rng.uniform(10, 6500, nsrc), rng.uniform(10, 4500, nsrc)
+    off, dep = np.sqrt(x * x + y * y), rng.uniform(1050, 4200, nsrc)
+    v = [3100.0, 2400.0, 3730.0, 4200.0, 5800.0, 4420.0, 6200.0]
+    d = [1000.0, 1500.0, 2000.0, 2500.0, 3260.0, 3960.0]
+    ev = T.GpuEvaluator(off, dep, np.zeros(nsrc), device=dev)
+    # observations = forward(true model) + N(0, 0.016 s), generated with the HIP path itself (synthetic data)
+    tt = rt.trace_device(torch.tensor(v, device=dev, dtype=torch.float64),
+                         torch.tensor(d, device=dev, dtype=torch.float64), ev.off, ev.dep).cpu().numpy()
+    ev.obs = torch.as_tensor(tt + rng.normal(0, 0.016, nsrc), device=dev)
+    nloc = 32
+    s = T.Sampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
+                  rank=rank, world=world, dist=dist if world > 1 else None, dist_device=str(dev))
+    s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)
+
+    def step():
+        s.sweep()
+        if world > 1 or nloc > 1:
+            s.swap_round()
+
+    m0 = [0]
+
+    def timed_step():
+        step()
+
+    for _ in range(args.warmup):
+        step()
+    m0[0] = ev.models
+    elapsed, _ = timed_steps(timed_step, args.steps, 0, world, dist if world > 1 else None, dev,
+                             sync=torch.cuda.synchronize)
+    models = ev.models - m0[0]
+    if world > 1:
+        tm = torch.tensor([float(models)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm)
+        models = float(tm[0])
+    if rank == 0:
+        res = {"metric": "travel-times/sec", "value": models * nsrc / elapsed, "unit": "travel-times/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,10], "
+                                      "swap round every sweep (BASELINE configs 3/4 shape)" % nsrc,
+                          "chains": nloc * world, "models_evaluated": models,
+                          "launches_per_step": ev.launches / max(1, args.steps + args.warmup),
+                          "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"])}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +226,9 @@ def main():
     ap.add_argument("--nsrc", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
+    ap.add_argument("--workload", choices=["c2", "pt"], default="c2",
+                    help="c2: single dff forward, 1e6 sources (the bench metric's configuration, default); "
+                         "pt: parallel-tempering sweeps, 32 chains per GPU x 1e4 sources (BASELINE configs 3/4 shape)")
     ap.add_argument("--path", choices=["auto", "plain", "fused"], default="auto",
                     help="kernel path of rtmi_trace_device (A/B runs; auto = what the library picks)")
     args = ap.parse_args()
@@ -196,6 +254,9 @@ def main():
     import raytracerfortran_amd as rt
     rt.load_library()
     rt.init(local_rank)
+
+    if args.workload == "pt":
+        return bench_pt(args, rt, torch, dist, rank, world, dev)
 
     n = args.nsrc
     v, d, off, dep = c2_workload(n, shard=rank)

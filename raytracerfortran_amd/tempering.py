@@ -1,0 +1,317 @@
+"""Parallel-tempering reversible-jump sampler over the GPU travel-time likelihood (host-driven).
+
+The reference runs one MPI rank per tempered chain; every Metropolis-Hastings decision re-traces all rays
+through `LOGLHOOD` -> `TraceRays` (/root/reference/ray_tracing_sampling/prjmh_temper_rf.f90:416-497,
+loglhood.f90:128-199).  Here the chains of a rank advance in lock-step: for every proposal slot of a sweep the
+proposed models of ALL local chains are evaluated by ONE `rtmi_trace_batch_device` launch (travel times + fused
+Gaussian logL on the GPU), the accept/reject decisions are taken on the host, and chains are sharded over ranks
+(one process per GPU).  A swap round all-gathers the chains' logL (`torch.distributed`: RCCL over xGMI for GPU
+tensors, gloo on CPU), after which every rank takes the SAME swap decisions from a shared random stream and swaps
+TEMPERATURES in place -- equivalent to the reference's "chain states swap, beta stays with the worker"
+(prjmh_temper_rf.f90:1351-1357) with no model state moving between GPUs.
+
+Proposal / prior semantics follow the reference configuration of test_1 (NPL = 2, ENOS = 0, IPOIPR = 1, ICOV = 1,
+I_VARPAR = 0):
+  state            k nodes (depth, Vp), node 1 pinned at depth 0; sigma               rjmcmc_com.f90:214-243
+  layering         nodes sorted by depth; vels = Vp of nodes, interfaces = depths of nodes 2..k
+                                                                                      loglhood.f90:214-260, :130-135
+  birth / death    1/3 each (none at the k limits); new node ~ U(0, hmx-hmin) x U(1500, 10000);
+                   logPr = log pk(k') - log pk(k), pk Poisson(lambda)                 prjmh_temper_rf.f90:669-713, :917-1095
+  perturbation     every (node, parameter) in turn, Cauchy step of scale (max-min)/30 prjmh_temper_rf.f90:721-759, :1387-1420
+  bounds           layer thickness >= hmin, interfaces <= hmx, depths in [0, hmx], Vp in [1500, 10000]
+                                                                                      prjmh_temper_rf.f90:1639-1716
+  sigma            with p = 0.9 a Gaussian step of (sdmx-sdmn)/10, bounds [sdmn, sdmx]  prjmh_temper_rf.f90:521-575, :1616-1630
+  acceptance       u < exp(logPr + beta (logL' - logL))                               prjmh_temper_rf.f90:697-706
+  ladder           beta_i = dTlog^-(i-1), NPTCHAINS1 chains at T = 1                   prjmh_temper_rf.f90:115-135
+  swap             u <= exp((beta2 - beta1)(logL1 - logL2))                           prjmh_temper_rf.f90:1329-1357
+Deliberate differences: the sigma step reuses the chain's residual sum instead of re-tracing identical rays; swap
+partners are adjacent temperature levels (alternating even/odd pairs) instead of "the first two workers that
+report to rank 0" (prjmh_temper_rf.f90:331-349), which depends on MPI timing.  Chain-level parity with the
+reference is therefore statistical, not bitwise (its RANDOM_NUMBER streams are compiler specific anyway).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+@dataclass
+class Prior:
+    """read_input.f90:205-214 + test_1_parameter.dat defaults."""
+    kmin: int = 1
+    kmax: int = 10
+    lam: float = 3.01          # Poisson prior on k
+    hmx: float = 10000.1       # max partition depth
+    hmin: float = 100.1        # min layer thickness
+    vmin: float = 1500.0
+    vmax: float = 10000.0
+    sdmin: float = 0.001
+    sdmax: float = 0.07
+    pertsdsc: float = 30.0     # read_input.f90:169
+    pertsdsdsc: float = 10.0   # read_input.f90:237
+
+    def log_pk(self, k: int) -> float:
+        return -self.lam + k * math.log(self.lam) - math.lgamma(k + 1.0)  # read_input.f90:78-81
+
+
+@dataclass
+class Chain:
+    nodes: np.ndarray          # [k, 2] (depth, Vp); row 0 is the surface node (depth pinned)
+    sd: float
+    logL: float = -np.inf
+    ss: float = np.inf         # sum of squared residuals of the current model
+
+    @property
+    def k(self) -> int:
+        return self.nodes.shape[0]
+
+
+def layering(nodes: np.ndarray):
+    """INTERPLAYER_novar (loglhood.f90:214-260) + LOGLHOOD_RT's call arguments (:130-144):
+    returns (vels[k], interfaces[k-1]) -- or the k = 1 special case (v, v), (9999.9,)."""
+    order = np.argsort(nodes[:, 0], kind="stable")
+    s = nodes[order]
+    if s.shape[0] == 1:
+        return np.array([s[0, 1], s[0, 1]]), np.array([9999.9])
+    return s[:, 1].copy(), s[1:, 0].copy()
+
+
+def inside_bounds(nodes: np.ndarray, pr: Prior) -> bool:
+    """CHECKBOUNDS (prjmh_temper_rf.f90:1639-1679)."""
+    k = nodes.shape[0]
+    if np.any(nodes[:, 1] < pr.vmin) or np.any(nodes[:, 1] > pr.vmax):
+        return False
+    if k > 1:
+        z = np.sort(nodes[:, 0])[1:]
+        if np.any(nodes[1:, 0] < 0.0) or np.any(nodes[1:, 0] > pr.hmx):
+            return False
+        h = np.diff(np.concatenate([[0.0], z]))
+        if np.any(h < pr.hmin) or np.any(z > pr.hmx):
+            return False
+    return True
+
+
+def gaussian_loglike(ss: float, n: int, sd: float) -> float:
+    """loglhood.f90:194-196 with the overflow-free normalisation."""
+    return -0.5 * n * LOG_2PI - (ss / (2.0 * sd * sd) + n * math.log(sd))
+
+
+class GpuEvaluator:
+    """logL of many models over the shared sources: one rtmi_trace_batch_device launch per call."""
+
+    def __init__(self, src_offset, src_depth, obs, device="cuda", ld: int = 32):
+        import torch
+        from . import raymod
+        self.torch, self.raymod, self.device, self.ld = torch, raymod, torch.device(device), ld
+        f64 = torch.float64
+        self.off = torch.as_tensor(np.asarray(src_offset, dtype=np.float64), device=self.device).to(f64).contiguous()
+        self.dep = torch.as_tensor(np.asarray(src_depth, dtype=np.float64), device=self.device).to(f64).contiguous()
+        self.obs = torch.as_tensor(np.asarray(obs, dtype=np.float64), device=self.device).to(f64).contiguous()
+        self.n = int(self.off.numel())
+        self.launches = 0
+        self.models = 0
+
+    def __call__(self, node_sets: List[np.ndarray]) -> np.ndarray:
+        """Sum of squared residuals of each model (the sigma-independent part of logL)."""
+        torch = self.torch
+        nm = len(node_sets)
+        if nm == 0:
+            return np.zeros(0)
+        V = np.zeros((nm, self.ld))
+        D = np.zeros((nm, self.ld))
+        NL = np.zeros(nm, np.int32)
+        for m, nodes in enumerate(node_sets):
+            v, z = layering(nodes)
+            if v.size > self.ld:
+                raise ValueError("model larger than ld")
+            V[m, :v.size], D[m, :z.size], NL[m] = v, z, z.size
+        one = torch.ones(nm, dtype=torch.float64, device=self.device)
+        _, L = self.raymod.trace_batch_device(torch.as_tensor(V, device=self.device), torch.as_tensor(D, device=self.device),
+                                              torch.as_tensor(NL, device=self.device), self.off, self.dep,
+                                              obs=self.obs, sd=one, want_timeP=False)
+        self.launches += 1
+        self.models += nm
+        # logL(sd = 1) = -(n/2) ln 2pi - SS/2  ->  SS
+        return (-2.0 * (L.cpu().numpy() + 0.5 * self.n * LOG_2PI))
+
+
+@dataclass
+class Sampler:
+    prior: Prior
+    evaluator: object                  # callable: list of node arrays -> SS per model
+    ndata: int
+    nchains_total: int
+    nptchains1: int = 1                # chains at T = 1
+    dTlog: float = 1.4
+    seed: int = 1
+    rank: int = 0
+    world: int = 1
+    dist: object = None                # torch.distributed (initialised) or None
+    dist_device: str = "cpu"           # device of the all-gather tensors ("cuda:<n>" -> RCCL)
+    chains: List[Chain] = field(default_factory=list)
+
+    def __post_init__(self):
+        assert self.nchains_total % self.world == 0, "chains must divide evenly over ranks"
+        self.nloc = self.nchains_total // self.world
+        self.first = self.rank * self.nloc
+        # temperature ladder (prjmh_temper_rf.f90:115-135): NPTCHAINS1 chains at T = 1, then one per level
+        levels = [0] * self.nptchains1 + list(range(1, self.nchains_total - self.nptchains1 + 1))
+        self.beta_of_level = np.array([self.dTlog ** (-lv) for lv in range(max(levels) + 1)])
+        self.level = np.array(levels)                      # level[c] of GLOBAL chain c, replicated on every rank
+        self.rng = np.random.default_rng([self.seed, self.rank])   # proposals: per-rank stream
+        self.rng_swap = np.random.default_rng([self.seed, 987654])  # swaps: SAME stream on every rank
+        self.stats = {"acc_bd": 0, "prop_bd": 0, "acc_mh": 0, "prop_mh": 0, "acc_sd": 0, "prop_sd": 0,
+                      "acc_swap": 0, "prop_swap": 0}
+        self.swap_parity = 0
+
+    # ----- initialisation -----------------------------------------------------------------------
+    def init_from_prior(self):
+        pr = self.prior
+        self.chains = []
+        while len(self.chains) < self.nloc:
+            k = int(self.rng.integers(max(pr.kmin, 1), min(pr.kmax, 4) + 1))
+            nodes = np.zeros((k, 2))
+            nodes[:, 1] = self.rng.uniform(pr.vmin, pr.vmax, k)
+            nodes[1:, 0] = self.rng.uniform(0.0, pr.hmx - pr.hmin, k - 1)
+            if inside_bounds(nodes, pr):
+                self.chains.append(Chain(nodes, float(self.rng.uniform(pr.sdmin, pr.sdmax))))
+        self._evaluate_current()
+
+    def init_from_model(self, nodes: np.ndarray, sd: float):
+        """Every chain starts at the <base>_map.dat model, as the reference does (prjmh_temper_rf.f90:152-189)."""
+        self.chains = [Chain(np.array(nodes, dtype=float).copy(), float(sd)) for _ in range(self.nloc)]
+        self._evaluate_current()
+
+    def _evaluate_current(self):
+        ss = self.evaluator([c.nodes for c in self.chains])
+        for c, s in zip(self.chains, ss):
+            c.ss = float(s)
+            c.logL = gaussian_loglike(c.ss, self.ndata, c.sd)
+
+    def beta(self, iloc: int) -> float:
+        return float(self.beta_of_level[self.level[self.first + iloc]])
+
+    # ----- one sweep of every local chain (EXPLORE_MH_NOVARPAR + EXPLORE_MH) ---------------------
+    def _decide(self, idx, proposals, logpr, kind):
+        """Evaluate the proposals of chains `idx` in one launch and apply the MH rule (:697-706, :742-751)."""
+        if not idx:
+            return
+        ss_new = self.evaluator(proposals)
+        for i, nodes, lp, s in zip(idx, proposals, logpr, ss_new):
+            c = self.chains[i]
+            logl_new = gaussian_loglike(float(s), self.ndata, c.sd)
+            log_ratio = lp + (logl_new - c.logL) * self.beta(i)
+            self.stats["prop_" + kind] += 1
+            if not (self.rng.random() >= math.exp(min(log_ratio, 50.0))):
+                c.nodes, c.ss, c.logL = nodes, float(s), logl_new
+                self.stats["acc_" + kind] += 1
+
+    def sweep(self):
+        pr = self.prior
+        rng = self.rng
+        # --- birth / death (:669-713) ---
+        idx, props, lps = [], [], []
+        if pr.kmin != pr.kmax:
+            for i, c in enumerate(self.chains):
+                u = rng.random()
+                k = c.k
+                move = 0
+                if k == pr.kmax:
+                    move = 2 if u <= 0.3333 else 0
+                elif k == pr.kmin:
+                    move = 1 if u <= 0.3333 else 0
+                else:
+                    move = 1 if u <= 0.3333 else (2 if u > 0.6666 else 0)
+                if move == 1:    # BIRTH_FULL (:997-1095)
+                    new = np.array([[(pr.hmx - pr.hmin) * rng.random(), pr.vmin + (pr.vmax - pr.vmin) * rng.random()]])
+                    nodes = np.vstack([c.nodes, new])
+                    lp = pr.log_pk(k + 1) - pr.log_pk(k)
+                elif move == 2 and k > 1:  # DEATH_FULL (:917-995): one of nodes 2..k
+                    idel = 1 + int(rng.integers(0, k - 1))
+                    nodes = np.delete(c.nodes, idel, axis=0)
+                    lp = pr.log_pk(k - 1) - pr.log_pk(k)
+                else:
+                    continue
+                if inside_bounds(nodes, pr):
+                    idx.append(i), props.append(nodes), lps.append(lp)
+                else:
+                    self.stats["prop_bd"] += 1
+        self._decide(idx, props, lps, "bd")
+        # --- perturbation of every (node, parameter) in turn (:721-759) ---
+        pert = np.array([(pr.hmx - pr.hmin) / pr.pertsdsc, (pr.vmax - pr.vmin) / pr.pertsdsc])
+        kmax_now = max(c.k for c in self.chains)
+        for ivo in range(kmax_now):
+            for ipar in (0, 1):
+                if ivo == 0 and ipar == 0:
+                    continue  # the surface node's depth is not a parameter (:727)
+                idx, props, lps = [], [], []
+                for i, c in enumerate(self.chains):
+                    if ivo >= c.k:
+                        continue
+                    nodes = c.nodes.copy()
+                    nodes[ivo, ipar] += pert[ipar] * math.tan(math.pi * (rng.random() - 0.5))  # PROPOSAL (:1405)
+                    if inside_bounds(nodes, pr):
+                        idx.append(i), props.append(nodes), lps.append(0.0)
+                    else:
+                        self.stats["prop_mh"] += 1
+                self._decide(idx, props, lps, "mh")
+        # --- sigma (EXPLORE_MH :521-575): same rays, so the residual sum is reused ---
+        step = (pr.sdmax - pr.sdmin) / pr.pertsdsdsc
+        for i, c in enumerate(self.chains):
+            if rng.random() >= 0.10:
+                sd_new = c.sd + step * rng.standard_normal()
+                self.stats["prop_sd"] += 1
+                if pr.sdmin <= sd_new <= pr.sdmax:
+                    logl_new = gaussian_loglike(c.ss, self.ndata, sd_new)
+                    if not (rng.random() >= math.exp(min((logl_new - c.logL) * self.beta(i), 50.0))):
+                        c.sd, c.logL = sd_new, logl_new
+                        self.stats["acc_sd"] += 1
+
+    # ----- temperature swaps (TEMPSWP_MH :1329-1357) ----------------------------------------------
+    def gather_logl(self) -> np.ndarray:
+        """logL of ALL chains, global order: the only data-path collective (one tiny all-gather per swap round)."""
+        local = np.array([c.logL for c in self.chains])
+        if self.dist is None or self.world == 1:
+            return local
+        import torch
+        t_loc = torch.as_tensor(local, dtype=torch.float64, device=self.dist_device)
+        t_all = torch.empty(self.nchains_total, dtype=torch.float64, device=self.dist_device)
+        self.dist.all_gather_into_tensor(t_all, t_loc)
+        return t_all.cpu().numpy()
+
+    def swap_round(self):
+        logl = self.gather_logl()
+        # chains ordered by level; partners = neighbours in that order, alternating even / odd pairs
+        order = np.argsort(self.level, kind="stable")
+        start = self.swap_parity
+        self.swap_parity ^= 1
+        for a in range(start, self.nchains_total - 1, 2):
+            c1, c2 = order[a], order[a + 1]
+            b1, b2 = self.beta_of_level[self.level[c1]], self.beta_of_level[self.level[c2]]
+            u = self.rng_swap.random()  # drawn on every rank, for every pair: identical streams
+            self.stats["prop_swap"] += 1
+            if b1 == b2:
+                continue
+            if u <= math.exp(min((b2 - b1) * (logl[c1] - logl[c2]), 50.0)):
+                self.level[c1], self.level[c2] = self.level[c2], self.level[c1]
+                self.stats["acc_swap"] += 1
+
+    # ----- driver ---------------------------------------------------------------------------------
+    def run(self, nsweeps: int, swap_every: int = 1, burnin: int = 0, thin: int = 1):
+        """Returns the T = 1 samples of the LOCAL chains: list of (k, nodes sorted by depth, sd, logL)."""
+        samples = []
+        for it in range(nsweeps):
+            self.sweep()
+            if (it + 1) % swap_every == 0 and self.nchains_total > 1:
+                self.swap_round()
+            if it >= burnin and (it - burnin) % thin == 0:
+                for i, c in enumerate(self.chains):
+                    if self.level[self.first + i] == 0:
+                        s = c.nodes[np.argsort(c.nodes[:, 0], kind="stable")]
+                        samples.append((c.k, s.copy(), c.sd, c.logL))
+        return samples
