@@ -79,6 +79,22 @@ def host_cores() -> int:
     return min(n, int(os.environ.get("RTMI_BENCH_MAX_THREADS", "64")))
 
 
+def measured_traffic(kernel_substr: str = "fused_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<tag>/pmc_summary.json, newest tag; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for k, c in d.items():
+            if kernel_substr in k and "hbm_bytes_per_launch" in c:
+                best = (c["hbm_bytes_per_launch"]["total"], os.path.relpath(path, ROOT))
+    return best
+
+
 def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
     """Time the CPU restatement on this host: all cores (threads over source slices; the C code
     holds no shared state and ctypes releases the GIL) and one core.  Bounded to ~budget_s."""
@@ -157,7 +173,8 @@ def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None,
     elapsed = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / steps if ev0 is not None else -1.0
     if dist is not None and world > 1:
-        tt = torch.tensor([elapsed, kern_ms], device=device, dtype=torch.float64)
+        red_dev = device if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([elapsed, kern_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(tt[0]), float(tt[1])
     return elapsed, (kern_ms if kern_ms >= 0 else None)
@@ -181,7 +198,8 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
     ev.obs = torch.as_tensor(tt + rng.normal(0, 0.016, nsrc), device=dev)
     nloc = 32
     s = T.Sampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
-                  rank=rank, world=world, dist=dist if world > 1 else None, dist_device=str(dev))
+                  rank=rank, world=world, dist=dist if world > 1 else None,
+                  dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)
 
     def step():
@@ -201,7 +219,8 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                              sync=torch.cuda.synchronize)
     models = ev.models - m0[0]
     if world > 1:
-        tm = torch.tensor([float(models)], device=dev, dtype=torch.float64)
+        tm = torch.tensor([float(models)], dtype=torch.float64,
+                          device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tm)
         models = float(tm[0])
     if rank == 0:
@@ -245,11 +264,17 @@ def main():
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL by default; RTMI_BENCH_BACKEND=gloo lets several ranks rehearse the N > 1 path on ONE GPU
+        backend = os.environ.get("RTMI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import raytracerfortran_amd as rt
     rt.load_library()
@@ -294,11 +319,22 @@ def main():
                        "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rtmi::fused_kernel<false>", "kernel_ms": kern_ms,
+                         "kernel": "rtmi::fused_kernel<false, true, false>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
                          "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; "
-                                 "see DESIGN.md"},
+                                 "see DESIGN.md section 4"},
         }
+        tr = measured_traffic()
+        if tr is not None and n == 1_000_000:
+            res["roofline"]["traffic"] = tr[0]
+            res["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        # the roof that actually binds: fp64 vector ALU.  Executed wave-instructions come from the same PMC passes
+        # (SQ_INSTS_VALU); ~1.4 flop per fp64 instruction (fma = 2, the rest 1).
+        res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                            "useful_fp64_instr_per_travel_time": 2600,
+                            "useful_instr_rate_T_per_s": 2600 * value / 1e12,
+                            "note": "useful = oracle-counted evaluations x layers x (1 sqrt + 2 div + 9 flops); "
+                                    "DESIGN.md section 4.2"}
         if check is not None:
             res["check_vs_oracle"] = check
         if world == 1 and not args.no_cpu_baseline:
