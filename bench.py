@@ -191,11 +191,11 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
     off, dep = np.sqrt(x * x + y * y), rng.uniform(1050, 4200, nsrc)
     v = [3100.0, 2400.0, 3730.0, 4200.0, 5800.0, 4420.0, 6200.0]
     d = [1000.0, 1500.0, 2000.0, 2500.0, 3260.0, 3960.0]
-    ev = T.GpuEvaluator(off, dep, np.zeros(nsrc), device=dev)
     # observations = forward(true model) + N(0, 0.016 s), generated with the HIP path itself (synthetic data)
-    tt = rt.trace_device(torch.tensor(v, device=dev, dtype=torch.float64),
-                         torch.tensor(d, device=dev, dtype=torch.float64), ev.off, ev.dep).cpu().numpy()
-    ev.obs = torch.as_tensor(tt + rng.normal(0, 0.016, nsrc), device=dev)
+    f64 = torch.float64
+    tt = rt.trace_device(torch.tensor(v, device=dev, dtype=f64), torch.tensor(d, device=dev, dtype=f64),
+                         torch.tensor(off, device=dev), torch.tensor(dep, device=dev)).cpu().numpy()
+    ev = T.GpuEvaluator(off, dep, tt + rng.normal(0, 0.016, nsrc))
     nloc = 32
     s = T.Sampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
                   rank=rank, world=world, dist=dist if world > 1 else None,

@@ -72,6 +72,24 @@ void rtmi_tracerays(const double *vels, const double *depths, const int *NLayers
 void rtmi_dff7(const double *vels, const double *depths, const int *NLayers, double *src_offset,
                double *src_depth, const int *NSrc, double *timeP);
 
+/*
+ * The likelihood as the sampler calls it: sources and observed times are read once (READDATA,
+ * read_input.f90:302-387) and then LOGLHOOD is evaluated for model after model
+ * (loglhood.f90:3-31 -> LOGLHOOD_RT :35-207; prjmh_temper_rf.f90:559,693,739).
+ *   rtmi_set_sources     copies src_offset / src_depth / obs (observed travel times, may be NULL
+ *                        if only forward calls follow) to HBM, where they stay.
+ *   rtmi_loglhood_batch  HOST arrays in and out: nmodels models (row m of vels / depths holds
+ *                        nlayers[m]+1 velocities / nlayers[m] interface depths, row stride
+ *                        ld_model), sd[m] = data standard deviation; returns
+ *                        logL[m] = -(N/2) ln 2pi - (SS/(2 sd^2) + N ln sd)   (loglhood.f90:194-196,
+ *                        ICOV = 1, one mode) and, if ss != NULL, SS = SUM(DresRT**2).  One launch
+ *                        for the whole batch; the travel times never leave the GPU.
+ * The k = 1 model is passed the way LOGLHOOD_RT does: nlayers = 1, vels = (v, v), depths = (9999.9).
+ */
+int rtmi_set_sources(const double *src_offset, const double *src_depth, const double *obs, int64_t nsrc);
+int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t *nlayers, int ld_model,
+                        int nmodels, const double *sd, double *logL, double *ss);
+
 /* ------------------------------------------------------------------------------------------
  * 2. Library state.
  * ------------------------------------------------------------------------------------------ */

@@ -53,6 +53,15 @@ struct Context {
     size_t model_cap = 0;
     double *d_src = nullptr;    // offset | depth | timeP | p_final
     size_t src_cap = 0;
+    // resident source set of the likelihood entry points (rtmi_set_sources)
+    double *d_set = nullptr;    // offset | depth | obs
+    size_t set_cap = 0;
+    int64_t set_n = 0;
+    bool set_has_obs = false;
+    double *d_lk = nullptr;     // models | sd | logL | ss | partial sums
+    size_t lk_cap = 0;
+    double *h_pin = nullptr;    // pinned staging of one batch (models in, logL/ss out)
+    size_t pin_cap = 0;
 };
 
 // Tuning knobs of the fused kernel, overridable from the environment for A/B runs.
@@ -254,6 +263,16 @@ int rtmi_init(int device)
             (void)hipFree(c.d_model);
         if (c.d_src)
             (void)hipFree(c.d_src);
+        if (c.d_set)
+            (void)hipFree(c.d_set);
+        if (c.d_lk)
+            (void)hipFree(c.d_lk);
+        if (c.h_pin)
+            (void)hipHostFree(c.h_pin);
+        c.d_set = c.d_lk = c.h_pin = nullptr;
+        c.set_cap = c.lk_cap = c.pin_cap = 0;
+        c.set_n = 0;
+        c.set_has_obs = false;
         if (c.stream)
             (void)hipStreamDestroy(c.stream);
         c.d_model = c.d_src = nullptr;
@@ -363,6 +382,116 @@ int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double 
     return RTMI_OK;
 }
 
+int rtmi_set_sources(const double *src_offset, const double *src_depth, const double *obs, int64_t nsrc)
+{
+    if (nsrc < 1 || !src_offset || !src_depth)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_set_sources: nsrc < 1 or NULL pointer");
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    int rc = ensure_ready_locked(c);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(c.device));
+    const size_t n = (size_t)nsrc;
+    rc = grow(&c.d_set, &c.set_cap, 3 * n);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_set, src_offset, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.d_set + n, src_depth, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    if (obs)
+        HIP_TRY(hipMemcpyAsync(c.d_set + 2 * n, obs, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    c.set_n = nsrc;
+    c.set_has_obs = obs != nullptr;
+    return RTMI_OK;
+}
+
+int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t *nlayers, int ld_model, int nmodels,
+                        const double *sd, double *logL, double *ss)
+{
+    if (nmodels < 0)
+        return fail(RTMI_ERR_BAD_ARG, "nmodels < 0");
+    if (nmodels == 0)
+        return RTMI_OK;
+    if (!vels || !depths || !nlayers || !sd || !logL)
+        return fail(RTMI_ERR_BAD_ARG, "NULL argument");
+    if (ld_model < 2 || ld_model - 1 > RTMI_MAX_LAYERS)
+        return fail(RTMI_ERR_BAD_ARG, "ld_model = %d outside [2, %d]", ld_model, RTMI_MAX_LAYERS + 1);
+    for (int m = 0; m < nmodels; ++m)
+        if (nlayers[m] < 1 || nlayers[m] > ld_model - 1)
+            return fail(RTMI_ERR_BAD_ARG, "nlayers[%d] = %d outside [1, ld_model - 1]", m, nlayers[m]);
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.ready || c.set_n < 1 || !c.set_has_obs)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_loglhood_batch: call rtmi_set_sources with observations first");
+    HIP_TRY(hipSetDevice(c.device));
+    const size_t nm = (size_t)nmodels, ld = (size_t)ld_model;
+    const size_t n_in = 2 * nm * ld + nm + (nm + 1) / 2;  // vels | depths | sd | nlayers (i32 packed)
+    const size_t n_out = 2 * nm;                           // logL | ss
+    const int64_t wbytes = rtmi_trace_batch_work_bytes(nmodels, c.set_n);
+    int rc = grow(&c.d_lk, &c.lk_cap, n_in + n_out + (size_t)wbytes / 8 + 8);
+    if (rc)
+        return rc;
+    if (c.pin_cap < n_in + n_out) {
+        if (c.h_pin)
+            HIP_TRY(hipHostFree(c.h_pin));
+        c.h_pin = nullptr;
+        c.pin_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&c.h_pin, (n_in + n_out + 1024) * sizeof(double), hipHostMallocDefault));
+        c.pin_cap = n_in + n_out + 1024;
+    }
+    double *h = c.h_pin;
+    memcpy(h, vels, nm * ld * sizeof(double));
+    memcpy(h + nm * ld, depths, nm * ld * sizeof(double));
+    memcpy(h + 2 * nm * ld, sd, nm * sizeof(double));
+    memcpy(h + 2 * nm * ld + nm, nlayers, nm * sizeof(int32_t));
+    double *d_v = c.d_lk, *d_d = d_v + nm * ld, *d_sd = d_d + nm * ld;
+    int32_t *d_nl = reinterpret_cast<int32_t *>(d_sd + nm);
+    double *d_out = c.d_lk + n_in;  // logL | ss
+    double *d_work = d_out + n_out;
+    HIP_TRY(hipMemcpyAsync(c.d_lk, h, n_in * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    const size_t n = (size_t)c.set_n;
+    // travel times are not materialised: only the residual sums leave the kernel
+    rtmi::FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    const Tuning tn = tuning();
+    int gx = 0;
+    if (tn.force_path != 1 && (c.set_n >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2)) {
+        fa.d_vels = d_v;
+        fa.d_depths = d_d;
+        fa.d_nlayers = d_nl;
+        fa.ld_model = ld_model;
+        fa.refill_min = tn.refill_min;
+        fa.d_src_offset = c.d_set;
+        fa.d_src_depth = c.d_set + n;
+        fa.nsrc = c.set_n;
+        fa.d_obs = c.d_set + 2 * n;
+        fa.d_partial = d_work;
+        HIP_TRY(rtmi_launch_fused(&fa, nmodels, ld_model - 1, c.cus, tn.solve_waves, &gx, c.stream));
+    } else {
+        rtmi::TraceArgs a;
+        memset(&a, 0, sizeof a);
+        a.d_vels = d_v;
+        a.d_depths = d_d;
+        a.d_nlayers = d_nl;
+        a.ld_model = ld_model;
+        a.d_src_offset = c.d_set;
+        a.d_src_depth = c.d_set + n;
+        a.nsrc = c.set_n;
+        a.d_obs = c.d_set + 2 * n;
+        a.d_partial = d_work;
+        gx = rtmi_launch_grid_x(c.set_n, nmodels, c.cus);
+        HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, c.stream));
+    }
+    HIP_TRY(rtmi_launch_loglike(d_work, gx, d_sd, c.set_n, nmodels, d_out, d_out + nm, c.stream));
+    HIP_TRY(hipMemcpyAsync(h + n_in, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    memcpy(logL, h + n_in, nm * sizeof(double));
+    if (ss)
+        memcpy(ss, h + n_in + nm, nm * sizeof(double));
+    return RTMI_OK;
+}
+
 int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc)
 {
     if (nmodels < 1 || nsrc < 0)
@@ -433,7 +562,8 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, (hipStream_t)stream));
     }
     if (want_ll)
-        HIP_TRY(rtmi_launch_loglike((const double *)d_work, gx, d_sd, nsrc, nmodels, d_logL, (hipStream_t)stream));
+        HIP_TRY(rtmi_launch_loglike((const double *)d_work, gx, d_sd, nsrc, nmodels, d_logL, nullptr,
+                                    (hipStream_t)stream));
     return RTMI_OK;
 }
 

@@ -61,7 +61,7 @@ int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);
 hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
                              hipStream_t stream);
 hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, const double *d_sd, int64_t ndat, int nmodels,
-                               double *d_logL, hipStream_t stream);
+                               double *d_logL, double *d_ss, hipStream_t stream);
 }
 
 #endif

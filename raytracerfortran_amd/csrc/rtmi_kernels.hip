@@ -132,7 +132,7 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgs a)
 
 // logL[m] = -(N/2) ln(2 pi) - ( SS/(2 sd^2) + N ln sd )     loglhood.f90:194-196
 __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, const double *__restrict__ sd,
-                               int64_t ndat, int nmodels, double *__restrict__ logL)
+                               int64_t ndat, int nmodels, double *__restrict__ logL, double *__restrict__ ss_out)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= nmodels)
@@ -144,6 +144,8 @@ __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, c
     const double n = (double)ndat;
     const double sdm = sd[m];
     logL[m] = -(n / 2.0) * log(2.0 * PI2) - (s / (2.0 * (sdm * sdm)) + n * log(sdm));
+    if (ss_out)
+        ss_out[m] = s;  // SUM(DresRT**2): lets a caller re-price sigma without re-tracing (loglhood.f90:195)
 }
 
 // =============================================================================================
@@ -527,12 +529,12 @@ extern "C" hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels
 }
 
 extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, const double *d_sd, int64_t ndat,
-                                          int nmodels, double *d_logL, hipStream_t stream)
+                                          int nmodels, double *d_logL, double *d_ss, hipStream_t stream)
 {
     const int block = 64;
     const int grid = (nmodels + block - 1) / block;
     hipLaunchKernelGGL(rtmi::loglike_kernel, dim3(grid), dim3(block), 0, stream, d_partial, nparts, d_sd, ndat,
-                       nmodels, d_logL);
+                       nmodels, d_logL, d_ss);
     return hipGetLastError();
 }
 

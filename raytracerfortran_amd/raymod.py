@@ -40,6 +40,9 @@ SIGNATURES = {
     "dff_": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp, _ip]),
     "rtmi_tracerays": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp, _ip]),
     "rtmi_dff7": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp]),
+    "rtmi_set_sources": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int64]),
+    "rtmi_loglhood_batch": (ctypes.c_int, [_dp, _dp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, _dp,
+                                            _dp, _dp]),
     "rtmi_init": (ctypes.c_int, [ctypes.c_int]),
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
@@ -170,6 +173,37 @@ def TraceRays(vels, depths, NLayers, src_offset, src_depth, NSrc, timeP=None, ke
 
 
 dofullforwardproblem = dff  # the Fortran-side name of `dff_` (subroutineR-quiet.f90:408)
+
+
+def set_sources(src_offset, src_depth, obs=None) -> None:
+    """READDATA's role (read_input.f90:302-387): sources and observed times go to HBM once (rtmi_set_sources)."""
+    lib = load_library()
+    off, dep = _as_f64(src_offset), _as_f64(src_depth)
+    if off.size != dep.size:
+        raise ValueError("src_offset / src_depth size mismatch")
+    o = _as_f64(obs, off.size, "obs") if obs is not None else None
+    _check(lib.rtmi_set_sources(off.ctypes.data_as(_dp), dep.ctypes.data_as(_dp),
+                                o.ctypes.data_as(_dp) if o is not None else None, off.size))
+
+
+def loglhood_batch(vels, depths, nlayers, sd, want_ss: bool = False):
+    """LOGLHOOD for a batch of models over the resident sources (rtmi_loglhood_batch).
+    vels, depths: [nmodels, ld] float64 host arrays; nlayers: [nmodels] int32; sd: [nmodels].
+    Returns logL[nmodels] (and SS[nmodels] with want_ss)."""
+    lib = load_library()
+    vels = np.ascontiguousarray(vels, dtype=np.float64)
+    depths = np.ascontiguousarray(depths, dtype=np.float64)
+    nl = np.ascontiguousarray(nlayers, dtype=np.int32)
+    sd = np.ascontiguousarray(sd, dtype=np.float64)
+    nm, ld = vels.shape
+    if depths.shape != (nm, ld) or nl.size != nm or sd.size != nm:
+        raise ValueError("shape mismatch")
+    logl = np.empty(nm)
+    ss = np.empty(nm) if want_ss else None
+    _check(lib.rtmi_loglhood_batch(vels.ctypes.data_as(_dp), depths.ctypes.data_as(_dp),
+                                   nl.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ld, nm, sd.ctypes.data_as(_dp),
+                                   logl.ctypes.data_as(_dp), ss.ctypes.data_as(_dp) if want_ss else None))
+    return (logl, ss) if want_ss else logl
 
 
 def write_rays_dat(path, vels, depths, src_offset, src_depth, p_final) -> None:

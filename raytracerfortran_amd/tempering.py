@@ -102,23 +102,21 @@ def gaussian_loglike(ss: float, n: int, sd: float) -> float:
 
 
 class GpuEvaluator:
-    """logL of many models over the shared sources: one rtmi_trace_batch_device launch per call."""
+    """Residual sums of many models over the resident sources: one rtmi_loglhood_batch call (one launch) per
+    proposal slot.  Sources and observations are uploaded once (rtmi_set_sources), like READDATA."""
 
-    def __init__(self, src_offset, src_depth, obs, device="cuda", ld: int = 32):
-        import torch
+    def __init__(self, src_offset, src_depth, obs, ld: int = 32):
         from . import raymod
-        self.torch, self.raymod, self.device, self.ld = torch, raymod, torch.device(device), ld
-        f64 = torch.float64
-        self.off = torch.as_tensor(np.asarray(src_offset, dtype=np.float64), device=self.device).to(f64).contiguous()
-        self.dep = torch.as_tensor(np.asarray(src_depth, dtype=np.float64), device=self.device).to(f64).contiguous()
-        self.obs = torch.as_tensor(np.asarray(obs, dtype=np.float64), device=self.device).to(f64).contiguous()
-        self.n = int(self.off.numel())
+        self.raymod, self.ld = raymod, ld
+        self.n = int(np.asarray(src_offset).size)
+        raymod.set_sources(src_offset, src_depth, obs)
         self.launches = 0
         self.models = 0
 
+    def set_observations(self, src_offset, src_depth, obs):
+        self.raymod.set_sources(src_offset, src_depth, obs)
+
     def __call__(self, node_sets: List[np.ndarray]) -> np.ndarray:
-        """Sum of squared residuals of each model (the sigma-independent part of logL)."""
-        torch = self.torch
         nm = len(node_sets)
         if nm == 0:
             return np.zeros(0)
@@ -130,14 +128,10 @@ class GpuEvaluator:
             if v.size > self.ld:
                 raise ValueError("model larger than ld")
             V[m, :v.size], D[m, :z.size], NL[m] = v, z, z.size
-        one = torch.ones(nm, dtype=torch.float64, device=self.device)
-        _, L = self.raymod.trace_batch_device(torch.as_tensor(V, device=self.device), torch.as_tensor(D, device=self.device),
-                                              torch.as_tensor(NL, device=self.device), self.off, self.dep,
-                                              obs=self.obs, sd=one, want_timeP=False)
+        _, ss = self.raymod.loglhood_batch(V, D, NL, np.ones(nm), want_ss=True)
         self.launches += 1
         self.models += nm
-        # logL(sd = 1) = -(n/2) ln 2pi - SS/2  ->  SS
-        return (-2.0 * (L.cpu().numpy() + 0.5 * self.n * LOG_2PI))
+        return ss
 
 
 @dataclass

@@ -383,6 +383,40 @@ def test_loglike_test_1_map(rt, kat):
     assert compare_times(T[0].cpu().numpy(), kat["config1_ref_timeP"], TOL) == 0.0
 
 
+def test_loglhood_batch_host_entry(rt, O, kat):
+    """rtmi_set_sources + rtmi_loglhood_batch: the likelihood as the sampler calls it (READDATA once, LOGLHOOD per
+    proposal; loglhood.f90:35-207), host arrays in and out."""
+    m = kat["model"]
+    off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
+    rt.set_sources(off, dep, obs)
+    V = np.zeros((3, 16)); D = np.zeros((3, 16)); NL = np.array([6, 1, 2], np.int32)
+    V[0, :7], D[0, :6] = m["vels"], m["depths"]
+    V[1, :2], D[1, 0] = 4321.0, 9999.9                       # k = 1 (loglhood.f90:137-144)
+    V[2, :3], D[2, :2] = [3000.0, 4500.0, 6000.0], [1200.0, 3000.0]
+    sd = np.array([0.02, 0.05, 0.03])
+    logl, ss = rt.loglhood_batch(V, D, NL, sd, want_ss=True)
+    assert abs(logl[0] - kat["test_1_map_logL_survey"]["value"]) < 1e-10 * 55.0
+    for i in range(3):
+        t = O.oracle_dff(V[i, :NL[i] + 1], D[i, :NL[i]], off, dep)
+        assert abs(logl[i] - O.oracle_loglhood_rt(obs, t, sd[i], stable=True)) <= 1e-11 * abs(logl[i])
+        assert abs(ss[i] - np.sum((np.array(obs) - t) ** 2)) <= 1e-12 * ss[i]
+    assert np.array_equal(rt.loglhood_batch(V, D, NL, sd), logl)   # deterministic
+    # a large resident set takes the fused kernel
+    v, d, off2, dep2 = c2_workload(50000, seed=21)
+    obs2 = O.oracle_dff(v, d, off2, dep2) + 0.01
+    obs2[obs2 < -900] = 1.0
+    rt.set_sources(off2, dep2, obs2)
+    V = np.zeros((2, 16)); D = np.zeros((2, 16)); NL = np.array([8, 8], np.int32)
+    V[:, :9], D[:, :8] = v, d
+    V[1, 4] += 50.0
+    l2 = rt.loglhood_batch(V, D, NL, np.array([0.02, 0.02]))
+    for i in range(2):
+        t = O.oracle_dff(V[i, :9], D[i, :8], off2, dep2)
+        assert abs(l2[i] - O.oracle_loglhood_rt(obs2, t, 0.02, stable=True)) <= 1e-11 * abs(l2[i])
+    with pytest.raises(rt.RtmiError):
+        rt.loglhood_batch(V, D, np.array([8, 99], np.int32), np.array([0.02, 0.02]))
+
+
 def test_many_layers(rt, O):
     """Up to the 1024-interface limit of the kernels (the reference's sampler copy stops at 99)."""
     rng = np.random.default_rng(8)

@@ -113,7 +113,7 @@ def test_tempered_run_on_test_1(kat):
     from oracle import oracle as O
     m = kat["model"]
     off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
-    ev = T.GpuEvaluator(off, dep, obs, device="cuda")
+    ev = T.GpuEvaluator(off, dep, obs)
     s = T.Sampler(T.Prior(), ev, ndata=20, nchains_total=8, nptchains1=1, dTlog=1.4, seed=2)
     nodes = np.column_stack([[0.0] + m["depths"], m["vels"]])
     s.init_from_model(nodes, 0.02)
