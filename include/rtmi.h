@@ -104,9 +104,11 @@ int rtmi_device_cus(void);
 /*
  * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
  *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel
- *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 3)
+ *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
- * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN.
+ *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
+ *                     fewer than g x tail_group remain queued, 0..4096 (default 512, 0 = off)
+ * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN, RTMI_TAIL_GROUP.
  */
 int rtmi_set_option(const char *name, int value);
 
@@ -164,8 +166,10 @@ int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double 
 /*
  * Diagnostic: while d_stamps != NULL, every fused-kernel launch of rtmi_trace_device writes, per
  * workgroup, the shader-clock ticks at {start, sorted, solved, times written} of its first round to
- * d_stamps[36*workgroup + 0..3], and per wave w {queue seen empty, last source finished} to
- * d_stamps[36*workgroup + 4 + 2w, + 5 + 2w] (device buffer of 36 x 8 B x 2 x CUs).  NULL switches off.
+ * d_stamps[100*workgroup + 0..3], and per wave w six words at d_stamps[100*workgroup + 4 + 6w ...]:
+ * {clock: queue seen empty, clock: last source finished, evaluation trips, sum of live lanes over trips,
+ * sum of layer-loop lengths over trips, useful layer terms | refill events << 40}
+ * (device buffer of 100 x 8 B x 2 x CUs).  NULL switches off.
  */
 int rtmi_debug_stamps(unsigned long long *d_stamps);
 

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""profiles/ab.py -- interleaved A/B of scheduling-knob settings of rtmi_trace_device in ONE process (same device,
+same clocks): for each setting the median / min kernel time over ROUNDS rounds of STEPS launches on the C2 workload."""
+import itertools, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracerfortran_amd as rt
+import bench
+rt.load_library(); rt.init(0)
+v, d, off, dep = bench.c2_workload(1_000_000)
+dev = "cuda"
+dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
+out = torch.empty(off.size, dtype=torch.float64, device=dev)
+settings = [dict(zip(("path", "waves_per_simd", "refill_min", "tail_group"), s)) for s in
+            [(2, w, m, t) for w in (4,) for m in (12, 16, 24) for t in (0, 384, 512, 768, 1024, 1536)]]
+ROUNDS, STEPS = 7, 10
+res = {i: [] for i in range(len(settings))}
+for r in range(ROUNDS):
+    for i, st in enumerate(settings):
+        for k, val in st.items():
+            rt.set_option(k, val)
+        rt.trace_device(dv, dd, do, dz, timeP=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(STEPS):
+            rt.trace_device(dv, dd, do, dz, timeP=out)
+        e1.record(); torch.cuda.synchronize()
+        res[i].append(e0.elapsed_time(e1) / STEPS)
+for i, st in enumerate(settings):
+    a = np.array(res[i])
+    print("%-70s median %.4f ms  min %.4f ms" % (st, np.median(a), a.min()))

@@ -11,14 +11,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 v, d, off, dep = bench.c2_workload(n)
 dev = "cuda"
 dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
-st = torch.zeros(36 * 512, dtype=torch.int64, device=dev)
+st = torch.zeros(100 * 512, dtype=torch.int64, device=dev)
 for _ in range(3):
     rt.trace_device(dv, dd, do, dz)
 lib.rtmi_debug_stamps(ctypes.c_void_p(st.data_ptr()))
 rt.trace_device(dv, dd, do, dz)
 torch.cuda.synchronize()
 lib.rtmi_debug_stamps(None)
-full = st.cpu().numpy().reshape(-1, 36)
+full = st.cpu().numpy().reshape(-1, 100)
 full = full[full[:, 0] != 0]
 s = full[:, :4]
 t0 = s[:, 0].min()
@@ -43,11 +43,16 @@ for b in range(nb):
     work[b] = nl[idx].sum()
 print("corr(solve ticks, sum nl) =", np.corrcoef(sol, work)[0, 1], " sum-nl cv =", work.std() / work.mean())
 
-wv = full[:, 4:].reshape(len(full), 16, 2).astype(float)
+wv = full[:, 4:].reshape(len(full), 16, 6).astype(np.int64)
 used = wv[:, :, 1] > 0
-dry = np.where(used, wv[:, :, 0], np.nan) - full[:, 1:2]      # since solve start
-fin = np.where(used, wv[:, :, 1], np.nan) - full[:, 1:2]
+dry = np.where(used, wv[:, :, 0], 0).astype(float) - full[:, 1:2]      # since solve start
+fin = np.where(used, wv[:, :, 1], 0).astype(float) - full[:, 1:2]
+dry[~used] = np.nan; fin[~used] = np.nan
 print("waves per workgroup:", used.sum(1).mean())
 print("queue seen empty (first wave)  mean %.0f   (last wave) mean %.0f" % (np.nanmin(dry, 1).mean(), np.nanmax(dry, 1).mean()))
 print("wave finished        (first)   mean %.0f   (last)      mean %.0f" % (np.nanmin(fin, 1).mean(), np.nanmax(fin, 1).mean()))
 print("mean over waves of (finish - empty): %.0f ticks" % np.nanmean(fin - dry))
+iters = wv[:, :, 2][used].sum(); busy = wv[:, :, 3][used].sum(); trips = wv[:, :, 4][used].sum()
+terms = (wv[:, :, 5][used] & ((1 << 40) - 1)).sum(); refills = (wv[:, :, 5][used] >> 40).sum()
+print("solve loop: %d wave-trips, live lanes per trip %.1f / 64, layer-loop length per trip %.2f" % (iters, busy / iters, trips / iters))
+print("useful layer terms %.3e of %.3e executed lane-terms = %.1f %%; refill events per trip %.3f" % (terms, trips * 64, 100.0 * terms / (trips * 64), refills / iters))

@@ -69,13 +69,14 @@ struct Tuning {
     int force_path;      // 0 auto, 1 plain kernel, 2 fused kernel
     int solve_waves;     // resident waves per SIMD of the fused kernel
     int refill_min;      // idle lanes that trigger a refill
+    int tail_group;      // end-game concentration (records per wave group), 0 = off
     unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
 };
 
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 3, 16, nullptr};
+        Tuning v{0, 4, 16, 512, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -86,6 +87,8 @@ Tuning &tuning()
             v.solve_waves = atoi(e) > 0 ? atoi(e) : v.solve_waves;
         if (const char *e = getenv("RTMI_REFILL_MIN"))
             v.refill_min = atoi(e) > 0 ? atoi(e) : v.refill_min;
+        if (const char *e = getenv("RTMI_TAIL_GROUP"))
+            v.tail_group = atoi(e) >= 0 ? atoi(e) : v.tail_group;
         return v;
     }();
     return t;
@@ -302,6 +305,10 @@ int rtmi_set_option(const char *name, int value)
         if (value < 1 || value > 64)
             return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
         t.refill_min = value;
+    } else if (!strcmp(name, "tail_group")) {
+        if (value < 0 || value > 4096)
+            return fail(RTMI_ERR_BAD_ARG, "tail_group must be in [0, 4096]");
+        t.tail_group = value;
     } else {
         return fail(RTMI_ERR_BAD_ARG, "unknown option %s", name);
     }
@@ -344,6 +351,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.d_depths = d_depths;
         fa.nlayers = nlayers;
         fa.refill_min = tn.refill_min;
+        fa.tail_group = tn.tail_group;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -462,6 +470,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.d_nlayers = d_nl;
         fa.ld_model = ld_model;
         fa.refill_min = tn.refill_min;
+        fa.tail_group = tn.tail_group;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
         fa.nsrc = c.set_n;
@@ -549,6 +558,7 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.d_nlayers = d_nlayers;
         fa.ld_model = ld_model;
         fa.refill_min = tn.refill_min;
+        fa.tail_group = tn.tail_group;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;

@@ -7,7 +7,7 @@
 
 #define RTMI_BLOCK 256          // threads per workgroup (4 waves: one per SIMD of a CU)
 #define RTMI_BLOCKS_PER_CU 16   // grid cap = CUs x this; further tiles are grid-strided
-#define RTMI_STAMPS_PER_WG 36  // diagnostic clocks per workgroup: 4 phase stamps + 2 per wave
+#define RTMI_STAMPS_PER_WG 100  // diagnostic words per workgroup: 4 phase clocks + 6 per wave
 #define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
 
 namespace rtmi {
@@ -38,6 +38,7 @@ struct FusedArgs {
     int ld_model;
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
+    int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
     const double *d_src_offset;  // [nsrc]
     const double *d_src_depth;   // [nsrc]
     int64_t nsrc;

@@ -364,18 +364,30 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
         s.numer_ok = true;
         int slot = 0;
         bool exhausted = false;  // wave-uniform: the queue head has passed n_todo
+        const int tail_group = a.tail_group < n_todo / 6 ? a.tail_group : n_todo / 6;  // short rounds: keep every wave fed
         int nfull_wave = 0;
+        // diagnostic occupancy counters (only touched when stamps are requested)
+        unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0;
         for (;;) {
             const unsigned long long idle = __ballot(s.st == ST_DONE);
             const int nidle = __popcll(idle);
+            // End-game concentration: the last records of the queue go to the first waves only (wave group g =
+            // wib / 4 stops refilling once fewer than g * tail_group records remain), so that the drain is
+            // carried by few, well filled waves instead of every wave at low occupancy.
+            if (!exhausted && tail_group > 0 && wib >= 4 && n_todo - (int)qctl[0] < (wib >> 2) * tail_group) {
+                exhausted = true;
+                if (stamps && j0 == 0 && lane == 0)
+                    stamps[4 + 6 * wib] = clock64();
+            }
             if (!exhausted && nidle >= a.refill_min) {
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(&qctl[0], (uint32_t)nidle);
                 base = __shfl(base, 0, 64);
                 exhausted = (int)base + nidle >= n_todo;
+                ++dg_refills;
                 if (stamps && j0 == 0 && exhausted && lane == 0)
-                    stamps[4 + 2 * wib] = clock64();  // this wave saw the queue run dry
+                    stamps[4 + 6 * wib] = clock64();  // this wave saw the queue run dry
                 if (s.st == ST_DONE) {
                     const int qi = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
                     if (qi < n_todo) {
@@ -398,14 +410,30 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             }
             if (__all(s.st == ST_DONE)) {
                 if (exhausted) {
-                    if (stamps && j0 == 0 && lane == 0)
-                        stamps[5 + 2 * wib] = clock64();  // this wave's last source finished
+                    if (stamps && j0 == 0 && lane == 0) {
+                        stamps[5 + 6 * wib] = clock64();  // this wave's last source finished
+                        stamps[6 + 6 * wib] = dg_iters;   // evaluation trips of the wave
+                        stamps[7 + 6 * wib] = dg_busy;    // sum over trips of lanes carrying a live source
+                        stamps[8 + 6 * wib] = dg_trips;   // sum over trips of layer-loop length (nfull_wave + 1)
+                        stamps[9 + 6 * wib] = dg_terms | (dg_refills << 40);  // useful layer terms | refill events
+                    }
                     break;
                 }
                 continue;  // all 64 lanes idle: the next trip refills
             }
             double f, fp;
             const bool was_busy = (s.st != ST_DONE);
+            if (stamps) {
+                const unsigned long long bm = __ballot(was_busy);
+                ++dg_iters;
+                dg_busy += (unsigned long long)__popcll(bm);
+                dg_trips += (unsigned long long)(nfull_wave + 1);
+                int terms = was_busy ? s.nfull + 1 : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    terms += __shfl_xor(terms, off, 64);
+                dg_terms += (unsigned long long)terms;
+            }
             eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
             lane_advance(s, f, fp);
             if (was_busy && s.st == ST_DONE) {

@@ -196,8 +196,8 @@ def test_trace_device_full_c2(rt, O):
 
 
 @pytest.mark.parametrize("n", [1, 64, 8192, 40001, 300000])
-@pytest.mark.parametrize("wps,refill", [(3, 16), (1, 1), (8, 64), (5, 7)])
-def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
+@pytest.mark.parametrize("wps,refill,tail", [(4, 16, 512), (1, 1, 0), (8, 64, 4096), (5, 7, 100), (3, 16, 0)])
+def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail):
     """Large source sets take the fused kernel (wave-local sort by layer, lane refill); small ones the plain
     one-lane-per-source kernel.  Same arithmetic per source: bit-identical results under every scheduling
     knob, final ray parameters included, with NaN data, straight rays, interface hits and -999 sources."""
@@ -218,12 +218,14 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill):
         rt.set_option("path", 2)
         rt.set_option("waves_per_simd", wps)
         rt.set_option("refill_min", refill)
+        rt.set_option("tail_group", tail)
         t2 = rt.trace_device(dv, dd, do, dz, p_final=p2).cpu().numpy()
         t3 = rt.trace_device(dv, dd, do, dz).cpu().numpy()  # without p_final
     finally:
         rt.set_option("path", 0)
-        rt.set_option("waves_per_simd", 3)
+        rt.set_option("waves_per_simd", 4)
         rt.set_option("refill_min", 16)
+        rt.set_option("tail_group", 512)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
     assert np.array_equal(t2, ref, equal_nan=True)
@@ -289,7 +291,7 @@ def test_fused_kernel_several_rounds(rt, O):
         t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
                             torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
     finally:
-        rt.set_option("waves_per_simd", 3)
+        rt.set_option("waves_per_simd", 4)
     assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
 
 
