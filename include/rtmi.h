@@ -134,6 +134,17 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
                       double *d_timeP, double *d_p_final, void *stream);
 
 /*
+ * The same forward evaluation in IEEE single precision (BASELINE config 5: "fp32 kernel path ...,
+ * delta-t tolerance vs fp64 reported").  Same algorithm, operation order and constants (each rounded
+ * to float) as the fp64 path; the reference has no single-precision build, so this entry point has
+ * no reference output to match: tests/test_gpu_parity.py checks it bit-for-bit against the CPU
+ * restatement built in single precision and reports its deviation from the fp64 result.
+ */
+int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayers,
+                          const float *d_src_offset, const float *d_src_depth, int64_t nsrc,
+                          float *d_timeP, float *d_p_final, void *stream);
+
+/*
  * Many models over one shared source set: what nmodels consecutive calls of
  * TraceRays from LOGLHOOD_RT compute (loglhood.f90:128-146), in one launch.
  *   d_vels   [nmodels][ld_model]   row m holds nlayers[m]+1 velocities

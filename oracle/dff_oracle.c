@@ -31,6 +31,28 @@
 #include <stdint.h>
 #include <string.h>
 
+/*
+ * One source, two builds: the default is the reference's precision (double).  -DORACLE_F32 builds the same
+ * restatement in IEEE single precision (every constant rounded to float, sqrtf, float divide) under the symbol
+ * suffix _f32: the checker of the fp32 kernel path (BASELINE config 5).  The reference itself has no single
+ * precision build of this module, so the fp32 oracle pins operation order, not a reference output.
+ */
+#ifdef ORACLE_F32
+typedef float real_t;
+#define R_SQRT sqrtf
+#define R_FABS fabsf
+#define R_ISNAN(x) isnan(x)
+#define C(x) ((real_t)(x))
+#define SYM(name) name##_f32
+#else
+typedef double real_t;
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_ISNAN(x) isnan(x)
+#define C(x) (x)
+#define SYM(name) name
+#endif
+
 #define ORACLE_MAX_STACK 4096 /* layers above one source; heap not needed below this */
 
 /* Optional per-call branch statistics; layout mirrored in oracle/oracle.py. */
@@ -51,27 +73,27 @@ typedef struct {
 static oracle_stats *g_stats = NULL; /* not thread safe: test use only */
 
 /* subroutineR-quiet.f90:9-32 whichLayer (returns 1-based layer index). */
-static int which_layer(const double *depths, int nlayers, double dph)
+static int which_layer(const real_t *depths, int nlayers, real_t dph)
 {
     int in_n = 0;
-    double diff = 0.0;
+    real_t diff = C(0.0);
     for (int i = 1; i <= nlayers; ++i) {
         in_n = i;
         diff = depths[i - 1] - dph;
-        if (diff > 0.0)
+        if (diff > C(0.0))
             break;
     }
-    if (diff < 0.0)
+    if (diff < C(0.0))
         return nlayers + 1;
     return in_n;
 }
 
 /* subroutineR-quiet.f90:184-202 costFunc */
-static double cost_func(double x, const double *H, const double *V, int n, double R)
+static real_t cost_func(real_t x, const real_t *H, const real_t *V, int n, real_t R)
 {
-    double sum_all = 0.0;
+    real_t sum_all = C(0.0);
     for (int i = 0; i < n; ++i) {
-        double term = ((H[i] * V[i]) * x) / sqrt(1.0 - (x * x) * (V[i] * V[i]));
+        real_t term = ((H[i] * V[i]) * x) / R_SQRT(C(1.0) - (x * x) * (V[i] * V[i]));
         sum_all = (i == 0) ? term : sum_all + term;
     }
     if (g_stats)
@@ -80,12 +102,12 @@ static double cost_func(double x, const double *H, const double *V, int n, doubl
 }
 
 /* subroutineR-quiet.f90:206-221 costFunc_Prime */
-static double cost_func_prime(double x, const double *H, const double *V, int n)
+static real_t cost_func_prime(real_t x, const real_t *H, const real_t *V, int n)
 {
-    double sum_all = 0.0;
+    real_t sum_all = C(0.0);
     for (int i = 0; i < n; ++i) {
-        double s = sqrt(1.0 - (x * x) * (V[i] * V[i]));
-        double term = (H[i] * V[i]) / ((s * s) * s);
+        real_t s = R_SQRT(C(1.0) - (x * x) * (V[i] * V[i]));
+        real_t term = (H[i] * V[i]) / ((s * s) * s);
         sum_all = (i == 0) ? term : sum_all + term;
     }
     if (g_stats)
@@ -93,9 +115,9 @@ static double cost_func_prime(double x, const double *H, const double *V, int n)
     return -sum_all;
 }
 
-static double max_val(const double *V, int n)
+static real_t max_val(const real_t *V, int n)
 {
-    double m = V[0];
+    real_t m = V[0];
     for (int i = 1; i < n; ++i)
         if (V[i] > m)
             m = V[i];
@@ -104,48 +126,48 @@ static double max_val(const double *V, int n)
 
 /* subroutineR-quiet.f90:226-332 solve (Newton, maxiter 15, tol 0.1).
  * Returns x; *conv follows the reference's inverted final test (:327-330). */
-static double solve_newton(double x0, const double *H, const double *V, int n, double R, int *conv)
+static real_t solve_newton(real_t x0, const real_t *H, const real_t *V, int n, real_t R, int *conv)
 {
     const int maxiter = 15;
-    const double tol = 1.e-1;
-    const double rr = 1e-9;
-    double x = x0, fx = 0.0, fxprime = 0.0;
+    const real_t tol = C(1.e-1);
+    const real_t rr = C(1e-9);
+    real_t x = x0, fx = C(0.0), fxprime = C(0.0);
     int k;
     *conv = 0;
     for (k = 1; k <= maxiter; ++k) {
         fx = cost_func(x, H, V, n, R);
         fxprime = cost_func_prime(x, H, V, n);
-        if (fabs(fx) < tol) {
+        if (R_FABS(fx) < tol) {
             *conv = 1;
             break;
         }
-        double deltax = fx / fxprime;
+        real_t deltax = fx / fxprime;
         x = x - deltax;
         if (g_stats)
             g_stats->newton_iters++;
-        if (x > 1.0 / max_val(V, n)) {
-            x = 1.0 / max_val(V, n) - rr;
+        if (x > C(1.0) / max_val(V, n)) {
+            x = C(1.0) / max_val(V, n) - rr;
             if (g_stats)
                 g_stats->clamps++;
         }
     }
     if (k > maxiter)
         fx = cost_func(x, H, V, n, R);
-    if (fabs(fx) > tol)
+    if (R_FABS(fx) > tol)
         *conv = 1;
     return x;
 }
 
 /* subroutineR-quiet.f90:339-405 solvebst (guarded bisection, maxiter 20). */
-static double solve_bisect(double x1, double x2, const double *H, const double *V, int n, double R)
+static real_t solve_bisect(real_t x1, real_t x2, const real_t *H, const real_t *V, int n, real_t R)
 {
     const int maxiter = 20;
-    const double tol = 1e-1;
-    double x, dx, fmid, f, fx, fxprime, xmid, deltax, check_x;
+    const real_t tol = C(1e-1);
+    real_t x, dx, fmid, f, fx, fxprime, xmid, deltax, check_x;
     fmid = cost_func(x2, H, V, n, R); /* :353 value is never used */
     f = cost_func(x1, H, V, n, R);
     (void)fmid;
-    if (f < 0.0) {
+    if (f < C(0.0)) {
         x = x1;
         dx = x2 - x1;
     } else {
@@ -155,22 +177,22 @@ static double solve_bisect(double x1, double x2, const double *H, const double *
     for (int k = 1; k <= maxiter; ++k) {
         if (g_stats)
             g_stats->bisect_trips++;
-        dx = dx * 0.5;
+        dx = dx * C(0.5);
         xmid = x + dx;
         fmid = cost_func(xmid, H, V, n, R);
-        if (fmid < 0.0)
+        if (fmid < C(0.0))
             x = xmid;
-        if (fmid == 0.0)
+        if (fmid == C(0.0))
             break;
         fx = cost_func(xmid, H, V, n, R);
         fxprime = cost_func_prime(xmid, H, V, n);
         deltax = fx / fxprime;
         check_x = x - deltax;
-        if (check_x < 1.0 / max_val(V, n) - (1e-10)) {
+        if (check_x < C(1.0) / max_val(V, n) - (C(1e-10))) {
             x = xmid;
             break;
         }
-        if (fabs(fmid) < tol)
+        if (R_FABS(fmid) < tol)
             break;
     }
     return x;
@@ -178,32 +200,32 @@ static double solve_bisect(double x1, double x2, const double *H, const double *
 
 /* subroutineR-quiet.f90:77-178 GetPTime for nl >= 2 (H, V are the stack above
  * the source, already differenced).  Writes the final ray parameter to *p_out. */
-static double get_ptime_stack(double src_depth, double src_offset, const double *H, const double *V,
-                              int n, double *p_out)
+static real_t get_ptime_stack(real_t src_depth, real_t src_offset, const real_t *H, const real_t *V,
+                              int n, real_t *p_out)
 {
     int conv = 0;
-    double s = 0.0;
+    real_t s = C(0.0);
     for (int i = 0; i < n; ++i) {
-        double q = H[i] / V[i];
+        real_t q = H[i] / V[i];
         s = (i == 0) ? q : s + q;
     }
-    double c_harmonic = src_depth / s;
-    double cos_t = src_depth / sqrt(src_offset * src_offset + src_depth * src_depth);
-    double weight = 1.0;
-    double p0 = cos_t / c_harmonic * weight;
+    real_t c_harmonic = src_depth / s;
+    real_t cos_t = src_depth / R_SQRT(src_offset * src_offset + src_depth * src_depth);
+    real_t weight = C(1.0);
+    real_t p0 = cos_t / c_harmonic * weight;
 
     /* :125-133.  The reference loops forever when p0 is NaN/Inf; the oracle
      * (like the HIP path) gives up after 4096 halvings and reports -999. */
     int guard = 0;
     for (;;) {
-        double acc = 0.0;
+        real_t acc = C(0.0);
         for (int i = 0; i < n; ++i) {
-            double t = sqrt(1.0 - (p0 * p0) * ((V[i] + 1.0) * (V[i] + 1.0)));
+            real_t t = R_SQRT(C(1.0) - (p0 * p0) * ((V[i] + C(1.0)) * (V[i] + C(1.0))));
             acc = (i == 0) ? t : acc + t;
         }
         if (!isnan(acc))
             break;
-        p0 = p0 / 2.0;
+        p0 = p0 / C(2.0);
         if (g_stats)
             g_stats->p0_halvings++;
         if (++guard > 4096) {
@@ -211,37 +233,37 @@ static double get_ptime_stack(double src_depth, double src_offset, const double 
                 *p_out = p0;
             if (g_stats)
                 g_stats->not_conv++;
-            return -999.0;
+            return -C(999.0);
         }
     }
 
-    double cf = cost_func(p0, H, V, n, src_offset);
-    double cfp = cost_func_prime(p0, H, V, n);
-    double check_x = p0 - cf / cfp;
-    double p_final;
-    if (cf < 0.0) {
+    real_t cf = cost_func(p0, H, V, n, src_offset);
+    real_t cfp = cost_func_prime(p0, H, V, n);
+    real_t check_x = p0 - cf / cfp;
+    real_t p_final;
+    if (cf < C(0.0)) {
         if (g_stats)
             g_stats->cf_negative++;
         p_final = solve_newton(p0, H, V, n, src_offset, &conv);
-    } else if (check_x < 1.0 / max_val(V, n) - (1e-10)) {
+    } else if (check_x < C(1.0) / max_val(V, n) - (C(1e-10))) {
         if (g_stats)
             g_stats->safe_jump++;
         p_final = solve_newton(p0, H, V, n, src_offset, &conv);
     } else {
         if (g_stats)
             g_stats->bisect++;
-        p_final = solve_bisect(1e-10, 1.0 / max_val(V, n) - 1e-12, H, V, n, src_offset);
+        p_final = solve_bisect(C(1e-10), C(1.0) / max_val(V, n) - C(1e-12), H, V, n, src_offset);
         p0 = p_final;
         p_final = solve_newton(p0, H, V, n, src_offset, &conv);
     }
-    double timeP = 0.0;
+    real_t timeP = C(0.0);
     for (int i = 0; i < n; ++i) {
-        double cosv = sqrt(1.0 - (p_final * p_final) * (V[i] * V[i]));
-        double t_int = H[i] / (V[i] * cosv);
+        real_t cosv = R_SQRT(C(1.0) - (p_final * p_final) * (V[i] * V[i]));
+        real_t t_int = H[i] / (V[i] * cosv);
         timeP = (i == 0) ? t_int : timeP + t_int;
     }
     if (!conv) {
-        timeP = -999.0;
+        timeP = -C(999.0);
         if (g_stats)
             g_stats->not_conv++;
     }
@@ -258,24 +280,24 @@ static double get_ptime_stack(double src_depth, double src_offset, const double 
  *   parameter (NaN for straight rays) and the 1-based source layer, from which
  *   the rays.dat records (:157-164) can be rebuilt -- see oracle_ray_segments.
  */
-void oracle_dff(const double *vels, const double *depths, int nlayers, const double *src_offset,
-                const double *src_depth, int64_t nsrc, double *timeP, double *p_final, int32_t *nl_out)
+void SYM(oracle_dff)(const real_t *vels, const real_t *depths, int nlayers, const real_t *src_offset,
+                const real_t *src_depth, int64_t nsrc, real_t *timeP, real_t *p_final, int32_t *nl_out)
 {
-    double Hs[ORACLE_MAX_STACK], Vs[ORACLE_MAX_STACK];
+    real_t Hs[ORACLE_MAX_STACK], Vs[ORACLE_MAX_STACK];
     for (int64_t k = 0; k < nsrc; ++k)
-        timeP[k] = -1.0; /* :430 */
+        timeP[k] = -C(1.0); /* :430 */
     if (nlayers + 1 > ORACLE_MAX_STACK)
         return;
     for (int64_t k = 0; k < nsrc; ++k) {
-        double dph = src_depth[k];
+        real_t dph = src_depth[k];
         int nl = which_layer(depths, nlayers, dph);
         if (nl_out)
             nl_out[k] = nl;
         if (nl == 1) {
             /* :94-97 straight ray in the top layer */
-            timeP[k] = sqrt(dph * dph + src_offset[k] * src_offset[k]) / vels[0];
+            timeP[k] = R_SQRT(dph * dph + src_offset[k] * src_offset[k]) / vels[0];
             if (p_final)
-                p_final[k] = NAN;
+                p_final[k] = C(NAN);
             if (g_stats)
                 g_stats->top_layer++;
             continue;
@@ -288,7 +310,7 @@ void oracle_dff(const double *vels, const double *depths, int nlayers, const dou
         for (int i = 1; i < nl - 1; ++i)
             Hs[i] = depths[i] - depths[i - 1];
         Hs[nl - 1] = dph - depths[nl - 2];
-        double p = 0.0;
+        real_t p = C(0.0);
         timeP[k] = get_ptime_stack(dph, src_offset[k], Hs, Vs, nl, &p);
         if (p_final)
             p_final[k] = p;
@@ -296,12 +318,12 @@ void oracle_dff(const double *vels, const double *depths, int nlayers, const dou
 }
 
 /* Same, collecting the branch statistics of SURVEY.md section 8(a). */
-void oracle_dff_stats(const double *vels, const double *depths, int nlayers, const double *src_offset,
-                      const double *src_depth, int64_t nsrc, double *timeP, oracle_stats *stats)
+void SYM(oracle_dff_stats)(const real_t *vels, const real_t *depths, int nlayers, const real_t *src_offset,
+                      const real_t *src_depth, int64_t nsrc, real_t *timeP, oracle_stats *stats)
 {
     memset(stats, 0, sizeof(*stats));
     g_stats = stats;
-    oracle_dff(vels, depths, nlayers, src_offset, src_depth, nsrc, timeP, NULL, NULL);
+    SYM(oracle_dff)(vels, depths, nlayers, src_offset, src_depth, nsrc, timeP, NULL, NULL);
     g_stats = NULL;
 }
 
@@ -312,8 +334,8 @@ void oracle_dff_stats(const double *vels, const double *depths, int nlayers, con
  * For nl == 1 the reference writes d = offset and h = depth.
  * Returns the number of segments written (nl), d and h sized >= nlayers+1.
  */
-int oracle_ray_segments(const double *vels, const double *depths, int nlayers, double src_offset,
-                        double src_depth, double p_final, double *d, double *h)
+int SYM(oracle_ray_segments)(const real_t *vels, const real_t *depths, int nlayers, real_t src_offset,
+                        real_t src_depth, real_t p_final, real_t *d, real_t *h)
 {
     int nl = which_layer(depths, nlayers, src_depth);
     if (nl == 1) {
@@ -322,21 +344,22 @@ int oracle_ray_segments(const double *vels, const double *depths, int nlayers, d
         return 1;
     }
     for (int i = 0; i < nl; ++i) {
-        double Hi;
+        real_t Hi;
         if (i == 0)
             Hi = depths[0];
         else if (i < nl - 1)
             Hi = depths[i] - depths[i - 1];
         else
             Hi = src_depth - depths[nl - 2];
-        double cosv = sqrt(1.0 - (p_final * p_final) * (vels[i] * vels[i]));
-        double q = Hi / cosv;
-        d[i] = sqrt(q * q - Hi * Hi);
+        real_t cosv = R_SQRT(C(1.0) - (p_final * p_final) * (vels[i] * vels[i]));
+        real_t q = Hi / cosv;
+        d[i] = R_SQRT(q * q - Hi * Hi);
         h[i] = Hi;
     }
     return nl;
 }
 
+#ifndef ORACLE_F32
 /*
  * Gaussian travel-time log-likelihood of one model, as LOGLHOOD_RT computes it
  * (/root/reference/ray_tracing_sampling/loglhood.f90:165-199, ICOV=1 branch):
@@ -360,3 +383,5 @@ double oracle_loglhood_rt(const double *obs, const double *pred, int64_t ndat, d
                          : log(1.0 / pow(2.0 * PI2, (double)ndat / 2.0));
     return norm - (ss / (2.0 * (sd * sd)) + (double)ndat * log(sd));
 }
+
+#endif

@@ -21,6 +21,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "liboracle_dff.so")
+_ORACLE_F32_SO = os.path.join(_HERE, "liboracle_dff_f32.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libdff_ref.so")
 _REF_O0_SO = os.path.join(_HERE, "_ref", "libdff_ref_O0.so")
 
@@ -41,8 +42,8 @@ class OracleStats(ctypes.Structure):
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (always) and oracle/_ref (only where possible)."""
-    if force or not os.path.exists(_ORACLE_SO) or (
-            os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "dff_oracle.c"))):
+    src_m = os.path.getmtime(os.path.join(_HERE, "dff_oracle.c"))
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < src_m for so in (_ORACLE_SO, _ORACLE_F32_SO)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
     if os.path.exists("/root/reference/subroutineR-quiet.f90") and (force or not os.path.exists(_REF_SO)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
@@ -120,6 +121,36 @@ def oracle_loglhood_rt(obs, pred, sd, stable: bool = False) -> float:
     lib = _oracle_lib()
     obs, pred = _f64(obs), _f64(pred)
     return float(lib.oracle_loglhood_rt(_p(obs), _p(pred), obs.size, float(sd), int(stable)))
+
+
+_lib32 = None
+
+
+def oracle_dff_f32(vels, depths, src_offset, src_depth, want_p: bool = False):
+    """The same restatement in IEEE single precision (dff_oracle.c built with -DORACLE_F32): the checker of the
+    fp32 kernel path.  float32 in, float32 out."""
+    global _lib32
+    if _lib32 is None:
+        build()
+        lib = ctypes.CDLL(_ORACLE_F32_SO)
+        fp = ctypes.POINTER(ctypes.c_float)
+        lib.oracle_dff_f32.argtypes = [fp, fp, ctypes.c_int, fp, fp, ctypes.c_int64, fp, fp,
+                                       ctypes.POINTER(ctypes.c_int32)]
+        lib.oracle_dff_f32.restype = None
+        _lib32 = lib
+    fp = ctypes.POINTER(ctypes.c_float)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    vels, depths, off, dep = f32(vels), f32(depths), f32(src_offset), f32(src_depth)
+    assert vels.size == depths.size + 1 and off.size == dep.size
+    n = off.size
+    t = np.empty(n, dtype=np.float32)
+    p = np.empty(n, dtype=np.float32) if want_p else None
+    nl = np.empty(n, dtype=np.int32) if want_p else None
+    _lib32.oracle_dff_f32(vels.ctypes.data_as(fp), depths.ctypes.data_as(fp), depths.size, off.ctypes.data_as(fp),
+                          dep.ctypes.data_as(fp), n, t.ctypes.data_as(fp),
+                          p.ctypes.data_as(fp) if want_p else None,
+                          nl.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if want_p else None)
+    return (t, p, nl) if want_p else t
 
 
 # ----------------------------------------------------------------------------------------------

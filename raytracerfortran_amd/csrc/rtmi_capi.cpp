@@ -501,6 +501,52 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
     return RTMI_OK;
 }
 
+int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayers, const float *d_src_offset,
+                          const float *d_src_depth, int64_t nsrc, float *d_timeP, float *d_p_final, void *stream)
+{
+    int rc = check_model(nlayers);
+    if (rc)
+        return rc;
+    if (nsrc < 0)
+        return fail(RTMI_ERR_BAD_ARG, "nsrc < 0");
+    if (nsrc == 0)
+        return RTMI_OK;
+    if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
+        return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
+    const Tuning tn = tuning();
+    const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
+    if (fused) {
+        rtmi::FusedArgsT<float> fa;
+        memset(&fa, 0, sizeof fa);
+        fa.d_vels = d_vels;
+        fa.d_depths = d_depths;
+        fa.nlayers = nlayers;
+        fa.refill_min = tn.refill_min;
+        fa.tail_group = tn.tail_group;
+        fa.d_src_offset = d_src_offset;
+        fa.d_src_depth = d_src_depth;
+        fa.nsrc = nsrc;
+        fa.d_timeP = d_timeP;
+        fa.d_p_final = d_p_final;
+        HIP_TRY(rtmi_launch_fused_f32(&fa, 1, nlayers, num_cus_for_current_device(), tn.solve_waves, nullptr,
+                                      (hipStream_t)stream));
+        return RTMI_OK;
+    }
+    rtmi::TraceArgsT<float> a;
+    memset(&a, 0, sizeof a);
+    a.d_vels = d_vels;
+    a.d_depths = d_depths;
+    a.nlayers = nlayers;
+    a.d_src_offset = d_src_offset;
+    a.d_src_depth = d_src_depth;
+    a.nsrc = nsrc;
+    a.d_timeP = d_timeP;
+    a.d_p_final = d_p_final;
+    const int gx = rtmi_launch_grid_x(nsrc, 1, num_cus_for_current_device());
+    HIP_TRY(rtmi_launch_trace_f32(&a, 1, nlayers, gx, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
 int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc)
 {
     if (nmodels < 1 || nsrc < 0)

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace rtmi {
 
 // Per-lane solver states.  One evaluation of (f, f') separates two transitions.
@@ -22,23 +24,25 @@ enum : int {
 
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of (nlayers + 1) doubles.
 #define RTMI_TABLE_ARRAYS 10
+template <typename T>
 struct LayerTable {
-    double *D;     // D[i]    depth to interface i                       i < nlayers
-    double *V;     // V[i]    velocity of layer i                        i <= nlayers
-    double *H;     // H[i]    thickness of a fully crossed layer i       i < nlayers
-    double *HV;    // HV[i]   H[i]*V[i]                                  i < nlayers
-    double *VV;    // VV[i]   V[i]*V[i]                                  i <= nlayers
-    double *PS;    // PS[i]   ((H0/V0 + H1/V1) + ...) + Hi/Vi            i < nlayers
-    double *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
-    double *VMI;   // VMI[i]  1/VMAX[i]                                  i <= nlayers
-    double *Q;     // scratch H[i]/V[i]
-    double *HVOK;  // HVOK[i] 1.0 if HV[0..i] are all 0 or of moderate magnitude (fast-path guard), else 0.0
+    T *D;     // D[i]    depth to interface i                       i < nlayers
+    T *V;     // V[i]    velocity of layer i                        i <= nlayers
+    T *H;     // H[i]    thickness of a fully crossed layer i       i < nlayers
+    T *HV;    // HV[i]   H[i]*V[i]                                  i < nlayers
+    T *VV;    // VV[i]   V[i]*V[i]                                  i <= nlayers
+    T *PS;    // PS[i]   ((H0/V0 + H1/V1) + ...) + Hi/Vi            i < nlayers
+    T *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
+    T *VMI;   // VMI[i]  1/VMAX[i]                                  i <= nlayers
+    T *Q;     // scratch H[i]/V[i]
+    T *HVOK;  // HVOK[i] 1.0 if HV[0..i] are all 0 or of moderate magnitude (fast-path guard), else 0.0
 };
 
-__device__ __forceinline__ LayerTable carve_table(double *lds, int nlayers)
+template <typename T>
+__device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers)
 {
     const int n1 = nlayers + 1;
-    LayerTable t;
+    LayerTable<T> t;
     t.D = lds;
     t.V = lds + n1;
     t.H = lds + 2 * n1;
@@ -54,6 +58,7 @@ __device__ __forceinline__ LayerTable carve_table(double *lds, int nlayers)
 
 // v == 0 or |v| inside (1e-30, 1e30): safe as one factor of a numerator of div_guarded (the product of two
 // such factors stays far from the exponent ranges where v_div_scale / v_div_fixup would act).
+__device__ __forceinline__ bool mag_ok(float) { return true; }  // the fp32 build has no guarded fast path
 __device__ __forceinline__ bool mag_ok(double v)
 {
     const double a = fabs(v);
@@ -65,16 +70,17 @@ __device__ __forceinline__ bool mag_ok(double v)
 //   (H*V) and (V*V) as separate products      costFunc :195, costFunc_Prime :214-219
 //   sum(depths/vp) left to right              GetPTime :112
 //   1/maxval(vp)                              :142, :148, :299, :388
-__device__ __forceinline__ void stage_model(const LayerTable &t, const double *__restrict__ vels,
-                                            const double *__restrict__ depths, int nlayers)
+template <typename T>
+__device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__restrict__ vels,
+                                            const T *__restrict__ depths, int nlayers)
 {
     for (int i = threadIdx.x; i <= nlayers; i += blockDim.x) {
-        const double v = vels[i];
+        const T v = vels[i];
         t.V[i] = v;
         t.VV[i] = v * v;
         if (i < nlayers) {
-            const double d = depths[i];
-            const double h = (i == 0) ? d : d - depths[i - 1];
+            const T d = depths[i];
+            const T h = (i == 0) ? d : d - depths[i - 1];
             t.D[i] = d;
             t.H[i] = h;
             t.HV[i] = h * v;
@@ -83,27 +89,27 @@ __device__ __forceinline__ void stage_model(const LayerTable &t, const double *_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double s = t.Q[0];
-        double m = t.V[0];
+        T s = t.Q[0];
+        T m = t.V[0];
         bool ok = mag_ok(t.HV[0]);
         t.PS[0] = s;
         t.VMAX[0] = m;
-        t.HVOK[0] = ok ? 1.0 : 0.0;
+        t.HVOK[0] = ok ? T(1.0) : T(0.0);
         for (int i = 1; i <= nlayers; ++i) {
-            const double v = t.V[i];
+            const T v = t.V[i];
             m = (v > m) ? v : m;  // maxval(): order-free
             t.VMAX[i] = m;
             if (i < nlayers) {
                 s = s + t.Q[i];
                 t.PS[i] = s;
                 ok = ok && mag_ok(t.HV[i]);
-                t.HVOK[i] = ok ? 1.0 : 0.0;
+                t.HVOK[i] = ok ? T(1.0) : T(0.0);
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= nlayers; i += blockDim.x)
-        t.VMI[i] = 1.0 / t.VMAX[i];
+        t.VMI[i] = T(1.0) / t.VMAX[i];
     __syncthreads();
 }
 
@@ -120,7 +126,8 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // whichLayer (:9-32): 1-based index of the first interface strictly below z; nlayers+1 below the
 // last one; nlayers when z sits exactly on the last interface (diff == 0 is neither > 0 nor < 0).
 // Wave-uniform loop with early exit; every lane of the wave must call it.
-__device__ __forceinline__ int which_layer(const LayerTable &t, int nlayers, double z)
+template <typename T>
+__device__ __forceinline__ int which_layer(const LayerTable<T> &t, int nlayers, T z)
 {
     int nl = 0;
     for (int i = 0; i < nlayers; ++i) {
@@ -131,7 +138,7 @@ __device__ __forceinline__ int which_layer(const LayerTable &t, int nlayers, dou
             break;
     }
     if (nl == 0)
-        nl = (t.D[nlayers - 1] - z < 0.0) ? nlayers + 1 : nlayers;
+        nl = (t.D[nlayers - 1] - z < T(0.0)) ? nlayers + 1 : nlayers;
     return nl;
 }
 
@@ -178,25 +185,25 @@ __device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-9
 // costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
 // `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
-template <bool FAST>
-__device__ __forceinline__ bool eval_terms(const LayerTable &t, double x, int nfull, int nfull_wave, double hvl,
-                                           double vvl, double R, double &f, double &fp)
+template <bool FAST, typename T>
+__device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
+                                           T vvl, T R, T &f, T &fp)
 {
-    const double xx = x * x;
-    double sf = 0.0, sp = 0.0;
+    const T xx = x * x;
+    T sf = T(0.0), sp = T(0.0);
     bool ok = true;
     for (int i = 0; i < nfull_wave; ++i) {
-        const double hv = t.HV[i];
-        const double vv = t.VV[i];
-        const double w = 1.0 - xx * vv;
-        double tf, tp;
-        if (FAST) {
+        const T hv = t.HV[i];
+        const T vv = t.VV[i];
+        const T w = T(1.0) - xx * vv;
+        T tf, tp;
+        if constexpr (FAST && std::is_same<T, double>::value) {
             ok = ok && (w > 1e-60 || i >= nfull);
             const double s = sqrt_guarded(w);
             tf = div_guarded(hv * x, s);
             tp = div_guarded(hv, (s * s) * s);
         } else {
-            const double s = sqrt(w);
+            const T s = sqrt(w);
             tf = (hv * x) / s;
             tp = hv / ((s * s) * s);
         }
@@ -206,14 +213,14 @@ __device__ __forceinline__ bool eval_terms(const LayerTable &t, double x, int nf
         }
     }
     {
-        const double w = 1.0 - xx * vvl;
-        if (FAST) {
+        const T w = T(1.0) - xx * vvl;
+        if constexpr (FAST && std::is_same<T, double>::value) {
             ok = ok && (w > 1e-60);
             const double s = sqrt_guarded(w);
             sf = sf + div_guarded(hvl * x, s);
             sp = sp + div_guarded(hvl, (s * s) * s);
         } else {
-            const double s = sqrt(w);
+            const T s = sqrt(w);
             sf = sf + (hvl * x) / s;
             sp = sp + hvl / ((s * s) * s);
         }
@@ -225,24 +232,30 @@ __device__ __forceinline__ bool eval_terms(const LayerTable &t, double x, int nf
 
 // `numer_ok`: lane-constant part of the guard (table products and hvl are 0 or of moderate magnitude).
 // `busy`: the lane carries a live source (idle lanes never veto the fast path).
-__device__ __forceinline__ void eval_f_fp(const LayerTable &t, double x, int nfull, int nfull_wave, double hvl,
-                                          double vvl, double R, bool numer_ok, bool busy, double &f, double &fp)
+template <typename T>
+__device__ __forceinline__ void eval_f_fp(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
+                                          T vvl, T R, bool numer_ok, bool busy, T &f, T &fp)
 {
-    const bool ok = eval_terms<true>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
-    if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
-        eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
+    if constexpr (std::is_same<T, double>::value) {
+        const bool ok = eval_terms<true>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
+        if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
+            eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
+    } else {
+        eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);  // fp32: plain IEEE sqrtf and divide
+    }
 }
 
 // Solver state of one source (one lane).
+template <typename T>
 struct Lane {
-    double R;     // src_offset
-    double hvl;   // (z - D[il-1]) * V[il]   partial layer of the source
-    double vvl;   // V[il]^2
-    double vmi;   // 1/maxval(vp)
-    double x;     // Newton iterate / final ray parameter
-    double xe;    // where the next (f, f') evaluation happens
-    double xb;    // bisection bracket end `x` of solvebst
-    double dx;
+    T R;     // src_offset
+    T hvl;   // (z - D[il-1]) * V[il]   partial layer of the source
+    T vvl;   // V[il]^2
+    T vmi;   // 1/maxval(vp)
+    T x;     // Newton iterate / final ray parameter
+    T xe;    // where the next (f, f') evaluation happens
+    T xb;    // bisection bracket end `x` of solvebst
+    T dx;
     int nfull;    // fully crossed layers = il
     int st;
     int k;        // trip counter of the current loop
@@ -251,46 +264,49 @@ struct Lane {
 };
 
 // The source's layer-dependent constants (InsertLayer :38-69 as table lookups).  il = nl - 1 >= 1.
-__device__ __forceinline__ void lane_setup(Lane &s, const LayerTable &t, int il, double R, double z)
+template <typename T>
+__device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, int il, T R, T z)
 {
-    const double vl = t.V[il];
-    const double hl = z - t.D[il - 1];  // depths_new(nl) - depths_new(nl-1)
+    const T vl = t.V[il];
+    const T hl = z - t.D[il - 1];  // depths_new(nl) - depths_new(nl-1)
     s.R = R;
     s.hvl = hl * vl;
     s.vvl = t.VV[il];
     s.vmi = t.VMI[il];
     s.nfull = il;
-    s.numer_ok = mag_ok(s.hvl) && (t.HVOK[il - 1] != 0.0);
+    s.numer_ok = mag_ok(s.hvl) && (t.HVOK[il - 1] != T(0.0));
 }
 
 // GetPTime head (:112-133): the starting ray parameter.  Returns NaN when the reference would loop
 // forever (NaN/Inf source data): such a source is reported as -999.
-__device__ __forceinline__ double initial_p0(const LayerTable &t, int il, double R, double z)
+template <typename T>
+__device__ __forceinline__ T initial_p0(const LayerTable<T> &t, int il, T R, T z)
 {
-    const double vl = t.V[il];
-    const double hl = z - t.D[il - 1];
-    const double c_harmonic = z / (t.PS[il - 1] + hl / vl);
-    const double cos_t = z / sqrt(R * R + z * z);
-    double p0 = cos_t / c_harmonic;
-    const double vmax = t.VMAX[il];
-    const double vm1sq = (vmax + 1.0) * (vmax + 1.0);
+    const T vl = t.V[il];
+    const T hl = z - t.D[il - 1];
+    const T c_harmonic = z / (t.PS[il - 1] + hl / vl);
+    const T cos_t = z / sqrt(R * R + z * z);
+    T p0 = cos_t / c_harmonic;
+    const T vmax = t.VMAX[il];
+    const T vm1sq = (vmax + T(1.0)) * (vmax + T(1.0));
     // sum(sqrt(1-(p0**2)*(vp+1)**2)) is NaN  <=>  (p0*p0)*(vmax+1)^2 > 1  (monotone in V; the
     // subtraction from 1 has the exact sign).
     int guard = 0;
-    while (!((p0 * p0) * vm1sq <= 1.0)) {
-        p0 = p0 / 2.0;
+    while (!((p0 * p0) * vm1sq <= T(1.0))) {
+        p0 = p0 / T(2.0);
         if (++guard > 2200 || p0 != p0)
-            return __builtin_nan("");
+            return T(__builtin_nan(""));
     }
     return p0;
 }
 
-__device__ __forceinline__ void lane_start(Lane &s, double p0)
+template <typename T>
+__device__ __forceinline__ void lane_start(Lane<T> &s, T p0)
 {
     s.x = p0;
     s.xe = p0;
-    s.xb = 0.0;
-    s.dx = 0.0;
+    s.xb = T(0.0);
+    s.dx = T(0.0);
     s.k = 0;
     s.conv = false;
     s.st = ST_INIT;
@@ -303,59 +319,60 @@ __device__ __forceinline__ void lane_start(Lane &s, double p0)
 // different states almost always, so a branchy dispatch executes every state's body on every trip;
 // the select form shares the common pieces (one quotient, one `check_x`, one Newton update).
 // Every value is computed by the same operation on the same operands as in the reference.
-__device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
+template <typename T>
+__device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
     const bool isI = (st == ST_INIT), isB0 = (st == ST_BIS0), isB = (st == ST_BIS), isN = (st == ST_NEWTON),
                isF = (st == ST_FINAL);
     // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294): same operands, one divide
-    const double q = f / fp;
-    const bool neg = f < 0.0;
-    const bool small = fabs(f) < 0.1;   // abs(fx) < tol (:287), abs(fmid) < tol (:394)
-    const double safe = s.vmi - 1e-10;  // 1/maxval(V)-(1d-10)      (:142, :388)
+    const T q = f / fp;
+    const bool neg = f < T(0.0);
+    const bool small = fabs(f) < T(0.1);   // abs(fx) < tol (:287), abs(fmid) < tol (:394)
+    const T safe = s.vmi - T(1e-10);  // 1/maxval(V)-(1d-10)      (:142, :388)
 
     // solvebst trip, first half: `if (fmid < 0) x = xmid` (:371-373)
-    const double xb1 = (isB && neg) ? s.xe : s.xb;
+    const T xb1 = (isB && neg) ? s.xe : s.xb;
     // check_x = p0 - cf/cfp (:138)  |  check_x = x - deltax (:386)
-    const double check_x = (isI ? s.xe : xb1) - q;
+    const T check_x = (isI ? s.xe : xb1) - q;
     const bool jump = check_x < safe;
 
     const bool initN = isI && (neg || jump);  // (:139-144) Newton straight from p0
     const bool initB = isI && !initN;         // (:145-148) bisection first
-    const bool zero = (f == 0.0);
+    const bool zero = (f == T(0.0));
     const bool bis_take = isB && !zero && jump;                                  // (:388-391) x = xmid; exit
     const bool bis_done = isB && (zero || jump || small || s.k == 20);           // (:375, :388, :394, maxiter)
     const bool bis_cont = isB && !bis_done;
-    const double xb2 = bis_take ? s.xe : xb1;
+    const T xb2 = bis_take ? s.xe : xb1;
 
     // solve trip (:269-311); for initN this evaluation is solve's first (x = p0)
     const bool newt = isN || initN;
-    const double xN = initN ? s.xe : s.x;
+    const T xN = initN ? s.xe : s.x;
     const int kN = initN ? 1 : s.k;
     const bool n_conv = newt && small;
     const bool n_go = newt && !small;
-    double xnew = xN - q;                // x = x - deltax (:298)
+    T xnew = xN - q;                // x = x - deltax (:298)
     if (xnew > s.vmi)
-        xnew = s.vmi - 1e-9;             // (:299-304)
+        xnew = s.vmi - T(1e-9);             // (:299-304)
 
     // solvebst entry (:354-365): x1 = 1d-10, x2 = 1/maxval(vp)-1d-12
-    const double x2 = s.vmi - 1e-12;
-    const double d21 = x2 - 1e-10;
-    const double xb0 = neg ? 1e-10 : x2;
-    const double dx0 = neg ? d21 : -d21;  // x2-x1 | x1-x2 (exact negation)
+    const T x2 = s.vmi - T(1e-12);
+    const T d21 = x2 - T(1e-10);
+    const T xb0 = neg ? T(1e-10) : x2;
+    const T dx0 = neg ? d21 : -d21;  // x2-x1 | x1-x2 (exact negation)
     // dx = dx*0.5; xmid = x + dx (:368-369) for the first and for every further trip
     const bool halve = isB0 || bis_cont;
-    const double dxh = (isB0 ? dx0 : s.dx) * 0.5;
-    const double xbh = isB0 ? xb0 : xb2;
-    const double xmid = xbh + dxh;
+    const T dxh = (isB0 ? dx0 : s.dx) * T(0.5);
+    const T xbh = isB0 ? xb0 : xb2;
+    const T xmid = xbh + dxh;
 
     // ---- commit -----------------------------------------------------------------------------
     s.xb = isB0 ? xb0 : (isB ? xb2 : s.xb);
     s.dx = halve ? dxh : s.dx;
     s.x = n_go ? xnew : (n_conv ? xN : (bis_done ? xb2 : s.x));
-    s.xe = initB ? 1e-10 : (halve ? xmid : (bis_done ? xb2 : (n_go ? xnew : s.xe)));
+    s.xe = initB ? T(1e-10) : (halve ? xmid : (bis_done ? xb2 : (n_go ? xnew : s.xe)));
     s.k = isB0 ? 1 : (bis_cont ? s.k + 1 : (bis_done ? 1 : ((n_go && kN != 15) ? kN + 1 : (initN ? 1 : s.k))));
-    s.conv = n_conv ? true : (isF ? (fabs(f) > 0.1) : s.conv);  // (:288) | the inverted test (:327-330)
+    s.conv = n_conv ? true : (isF ? (fabs(f) > T(0.1)) : s.conv);  // (:288) | the inverted test (:327-330)
     s.st = initB ? ST_BIS0
                  : (isB0 || bis_cont) ? ST_BIS
                                       : bis_done ? ST_NEWTON
@@ -364,19 +381,20 @@ __device__ __forceinline__ void lane_advance(Lane &s, double f, double fp)
 }
 
 // Travel time for a known ray parameter (:156, :165-166).  Wave-uniform loop.
-__device__ __forceinline__ double travel_time(const LayerTable &t, double p, int nfull, int nfull_wave, int il,
-                                              double z)
+template <typename T>
+__device__ __forceinline__ T travel_time(const LayerTable<T> &t, T p, int nfull, int nfull_wave, int il,
+                                              T z)
 {
-    const double pp = p * p;
-    double tt = 0.0;
+    const T pp = p * p;
+    T tt = T(0.0);
     for (int i = 0; i < nfull_wave; ++i) {
-        const double cosv = sqrt(1.0 - pp * t.VV[i]);
-        const double ti = t.H[i] / (t.V[i] * cosv);
+        const T cosv = sqrt(T(1.0) - pp * t.VV[i]);
+        const T ti = t.H[i] / (t.V[i] * cosv);
         if (i < nfull)
             tt = tt + ti;
     }
-    const double hl = z - t.D[il - 1];
-    const double cosv = sqrt(1.0 - pp * t.VV[il]);
+    const T hl = z - t.D[il - 1];
+    const T cosv = sqrt(T(1.0) - pp * t.VV[il]);
     tt = tt + hl / (t.V[il] * cosv);
     return tt;
 }

@@ -12,48 +12,57 @@
 
 namespace rtmi {
 
-// Kernel arguments of one trace launch.  Every pointer is a device pointer.
-struct TraceArgs {
-    const double *d_vels;      // [nmodels][ld_model]
-    const double *d_depths;    // [nmodels][ld_model]
+// Kernel arguments of one trace launch.  Every pointer is a device pointer.  T = double (the reference's
+// precision) or float (BASELINE config 5).
+template <typename T>
+struct TraceArgsT {
+    const T *d_vels;      // [nmodels][ld_model]
+    const T *d_depths;    // [nmodels][ld_model]
     const int32_t *d_nlayers;  // [nmodels] or NULL -> `nlayers` for every model
     int nlayers;
     int ld_model;
-    const double *d_src_offset;  // [nsrc]
-    const double *d_src_depth;   // [nsrc]
+    const T *d_src_offset;  // [nsrc]
+    const T *d_src_depth;   // [nsrc]
     int64_t nsrc;
-    double *d_timeP;    // [nmodels][nsrc] or NULL
-    double *d_p_final;  // [nsrc] or NULL (single model only)
-    const double *d_obs;  // [nsrc] or NULL
-    double *d_partial;    // [nmodels][grid_x] per-workgroup sums of squared residuals
+    T *d_timeP;    // [nmodels][nsrc] or NULL
+    T *d_p_final;  // [nsrc] or NULL (single model only)
+    const T *d_obs;  // [nsrc] or NULL
+    T *d_partial;    // [nmodels][grid_x] per-workgroup sums of squared residuals
 };
+typedef TraceArgsT<double> TraceArgs;
 
 // Arguments of the fused large-NSrc kernel.  Model m = blockIdx.y uses row m of d_vels / d_depths.
-#define RTMI_SLOT_BYTES 34  // LDS per queued record: offset, depth, p (f64) + key, nl scratch (u32) + order (u16)
-struct FusedArgs {
-    const double *d_vels;        // [nmodels][ld_model]
-    const double *d_depths;      // [nmodels][ld_model]
+#define RTMI_SLOT_BYTES(T) (3 * sizeof(T) + 10)  // LDS per queued record: offset, depth, p + key, nl scratch (u32) + order (u16)
+template <typename T>
+struct FusedArgsT {
+    const T *d_vels;        // [nmodels][ld_model]
+    const T *d_depths;      // [nmodels][ld_model]
     const int32_t *d_nlayers;    // [nmodels] or NULL -> `nlayers` for every model
     int nlayers;
     int ld_model;
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
-    const double *d_src_offset;  // [nsrc]
-    const double *d_src_depth;   // [nsrc]
+    const T *d_src_offset;  // [nsrc]
+    const T *d_src_depth;   // [nsrc]
     int64_t nsrc;
-    double *d_timeP;             // [nmodels][nsrc] or NULL
-    double *d_p_final;           // [nsrc] or NULL (single model only)
-    const double *d_obs;         // [nsrc] or NULL
-    double *d_partial;           // [nmodels][grid.x] per-workgroup sums of squared residuals
+    T *d_timeP;             // [nmodels][nsrc] or NULL
+    T *d_p_final;           // [nsrc] or NULL (single model only)
+    const T *d_obs;         // [nsrc] or NULL
+    T *d_partial;           // [nmodels][grid.x] per-workgroup sums of squared residuals
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
 };
+typedef FusedArgsT<double> FusedArgs;
 
 }  // namespace rtmi
 
 extern "C" {
-int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd, int *threads,
-                        int *slots, size_t *lds_bytes);
+int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd, int elem_bytes,
+                        int *threads, int *slots, size_t *lds_bytes);
+hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers, int num_cus,
+                                 int waves_per_simd, int *grid_x_out, hipStream_t stream);
+hipError_t rtmi_launch_trace_f32(const rtmi::TraceArgsT<float> *args, int nmodels, int max_nlayers, int grid_x,
+                                 hipStream_t stream);
 hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
                              int waves_per_simd, int *grid_x_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,

@@ -48,30 +48,30 @@ namespace rtmi {
 
 // One source per lane, all lanes of the wave together (wave-uniform loops inside);
 // `valid` = false lanes carry a dummy source and their result is discarded.
-__device__ __forceinline__ double trace_one(const LayerTable &t, int nlayers, double R, double z, bool valid,
-                                            double &p_out)
+template <typename T>
+__device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R, T z, bool valid, T &p_out)
 {
     const int nl = which_layer(t, nlayers, z);
     const bool straight = (nl == 1);  // source in the top layer (:94-97)
     const bool active = valid && !straight;
     const int il = active ? nl - 1 : 1;  // 0-based layer of the source; dummy lanes use layer 1
-    Lane s;
+    Lane<T> s;
     lane_setup(s, t, il, R, z);
-    const double p0 = active ? initial_p0(t, il, R, z) : 0.0;
+    const T p0 = active ? initial_p0(t, il, R, z) : T(0.0);
     lane_start(s, p0);
     if (!active || p0 != p0)
         s.st = ST_DONE;
     const int nfull_wave = wave_max_i32(active ? s.nfull : 0);
 
     while (__any(s.st != ST_DONE)) {
-        double f, fp;
+        T f, fp;
         eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, s.st != ST_DONE, f, fp);
         lane_advance(s, f, fp);
     }
 
-    double tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z);
+    T tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z);
     if (!s.conv)
-        tt = -999.0;
+        tt = -T(999.0);
     p_out = s.x;
     if (straight) {
         tt = sqrt(z * z + R * R) / t.V[0];
@@ -81,32 +81,33 @@ __device__ __forceinline__ double trace_one(const LayerTable &t, int nlayers, do
 }
 
 // grid.x: source tiles (grid-stride), grid.y: models.
-template <bool WANT_P, bool WANT_T, bool WANT_SS>
-__global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgs a)
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS>
+__global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_raw[];  // 8-byte aligned storage for either element type
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     const int nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
-    const LayerTable t = carve_table(lds, nlayers);
+    const LayerTable<T> t = carve_table(lds, nlayers);
     stage_model(t, a.d_vels + (int64_t)m * a.ld_model, a.d_depths + (int64_t)m * a.ld_model, nlayers);
 
-    double ss = 0.0;  // this thread's sum of squared residuals (fused logL)
-    double *out = a.d_timeP + (int64_t)m * a.nsrc;
+    T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
+    T *out = a.d_timeP + (int64_t)m * a.nsrc;
     const int64_t ntiles = (a.nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t k = tile * RTMI_BLOCK + threadIdx.x;
         const bool valid = k < a.nsrc;
-        const double R = valid ? a.d_src_offset[k] : 1.0;
-        const double z = valid ? a.d_src_depth[k] : 1.0;
-        double p;
-        const double tt = trace_one(t, nlayers, R, z, valid, p);
+        const T R = valid ? a.d_src_offset[k] : T(1.0);
+        const T z = valid ? a.d_src_depth[k] : T(1.0);
+        T p;
+        const T tt = trace_one(t, nlayers, R, z, valid, p);
         if (valid) {
             if (WANT_T)
                 out[k] = tt;
             if (WANT_P)
                 a.d_p_final[k] = p;
             if (WANT_SS) {
-                const double r = a.d_obs[k] - tt;
+                const T r = a.d_obs[k] - tt;
                 ss = ss + r * r;
             }
         }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgs a)
 
     if (WANT_SS) {
         // block reduction in a fixed order: lanes by xor-butterfly, then waves 0..3
-        __shared__ double wsum[RTMI_BLOCK / 64];
+        __shared__ T wsum[RTMI_BLOCK / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             ss = ss + __shfl_xor(ss, off, 64);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgs a)
             wsum[threadIdx.x >> 6] = ss;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double s = wsum[0];
+            T s = wsum[0];
             for (int w = 1; w < RTMI_BLOCK / 64; ++w)
                 s = s + wsum[w];
             a.d_partial[(int64_t)m * gridDim.x + blockIdx.x] = s;
@@ -167,27 +168,29 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
 // grid.y = model (many models over one shared source set: loglhood.f90:128-146 per proposal); every
 // workgroup row b of a model owns chunks b, b + gridDim.x, ... of the sources.
-template <bool WANT_P, bool WANT_T, bool WANT_SS>
-__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a)
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_raw[];  // 8-byte aligned storage for either element type
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
     a.d_vels += (int64_t)m * a.ld_model;
     a.d_depths += (int64_t)m * a.ld_model;
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
-    const LayerTable t = carve_table(lds, a.nlayers);
+    const LayerTable<T> t = carve_table(lds, a.nlayers);
     stage_model(t, a.d_vels, a.d_depths, a.nlayers);
-    double ss = 0.0;  // this thread's sum of squared residuals (fused logL)
+    T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int nwib = blockDim.x >> 6;
     const int slots = a.slots;
-    double *rR = lds + RTMI_TABLE_ARRAYS * (a.nlayers + 1);  // offset            } records of the current round,
-    double *rz = rR + slots;                                  // depth             } sorted by descending layer
-    double *rp = rz + slots;                                  // p0, later p_final }
+    T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
+                                  ((size_t)RTMI_TABLE_ARRAYS * (a.nlayers + 1) * sizeof(T) + 7) / 8 * 8);  // offset }
+    T *rz = rR + slots;                                  // depth             } sorted by descending layer
+    T *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
     uint32_t *tnl = rk + slots;                               // nl per local index (between the sort passes)
     uint32_t *hist = tnl + slots;                             // [16 waves][64 bins] counts, then first slots
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 break;
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const double z = valid ? a.d_src_depth[k] : 0.0;
+            const T z = valid ? a.d_src_depth[k] : T(0.0);
             int nl = which_layer(t, a.nlayers, z);
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
@@ -283,17 +286,17 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 todo &= ~grp;
             }
             if (valid) {
-                const double R = a.d_src_offset[k];
-                const double z = a.d_src_depth[k];
+                const T R = a.d_src_offset[k];
+                const T z = a.d_src_depth[k];
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
-                    const double tt = sqrt(z * z + R * R) / t.V[0];
+                    const T tt = sqrt(z * z + R * R) / t.V[0];
                     if (WANT_T)
                         a.d_timeP[k] = tt;
                     if (WANT_P)
                         a.d_p_final[k] = __builtin_nan("");
                     if (WANT_SS) {
-                        const double r = a.d_obs[k] - tt;
+                        const T r = a.d_obs[k] - tt;
                         ss = ss + r * r;
                     }
                 } else {
@@ -316,17 +319,17 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
         for (int q0 = wib * 64; q0 < nq; q0 += nwib * 64) {
             const int q = q0 + lane;
             const bool valid = q < nq;
-            Lane s;
+            Lane<T> s;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
             const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
-            const double p0 = valid ? rp[q] : 0.0;
-            lane_setup(s, t, nl - 1, valid ? rR[q] : 1.0, valid ? rz[q] : 1.0);
+            const T p0 = valid ? rp[q] : T(0.0);
+            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
             lane_start(s, p0);
             const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
             if (!live)
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
-            double f, fp;
+            T f, fp;
             eval_f_fp(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
             if (live)
                 lane_advance(s, f, fp);
@@ -355,10 +358,10 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             stamps[1] = clock64();
 
         // ---- b. solve: every wave pulls from the workgroup's queue, lanes refill as they finish ----
-        Lane s;
+        Lane<T> s;
         s.st = ST_DONE;
         s.nfull = 0;
-        s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = 0.0;
+        s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = T(0.0);
         s.k = 0;
         s.conv = false;
         s.numer_ok = true;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 }
                 continue;  // all 64 lanes idle: the next trip refills
             }
-            double f, fp;
+            T f, fp;
             const bool was_busy = (s.st != ST_DONE);
             if (stamps) {
                 const unsigned long long bm = __ballot(was_busy);
@@ -452,12 +455,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             const bool valid = q < nq;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
             const int il = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu) - 1;
-            const double p = valid ? rp[q] : 0.0;
-            const double z = valid ? rz[q] : 1.0;
+            const T p = valid ? rp[q] : T(0.0);
+            const T z = valid ? rz[q] : T(1.0);
             const int nfw = wave_max_i32(valid ? il : 0);
-            double tt = travel_time(t, p, il, nfw, il, z);
+            T tt = travel_time(t, p, il, nfw, il, z);
             if (!(key & RTMI_RK_CONV))
-                tt = -999.0;
+                tt = -T(999.0);
             if (valid) {
                 const int loc = (int)(key & RTMI_RK_LOC_MASK);
                 const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
                 if (WANT_P)
                     a.d_p_final[k] = p;
                 if (WANT_SS) {
-                    const double r = a.d_obs[k] - tt;
+                    const T r = a.d_obs[k] - tt;
                     ss = ss + r * r;
                 }
             }
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
 
     if (WANT_SS) {
         // workgroup reduction in a fixed order: lanes by xor-butterfly, then waves 0..nwib-1
-        double *wsum = rR;  // the record area is free now (the round loop ended with a barrier)
+        T *wsum = rR;  // the record area is free now (the round loop ended with a barrier)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             ss = ss + __shfl_xor(ss, off, 64);
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgs a
             wsum[wib] = ss;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double tot = wsum[0];
+            T tot = wsum[0];
             for (int w = 1; w < nwib; ++w)
                 tot = tot + wsum[w];
             a.d_partial[(int64_t)m * gridDim.x + blockIdx.x] = tot;
@@ -535,25 +538,37 @@ extern "C" int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus)
     return (int)g;
 }
 
-extern "C" hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
-                                        hipStream_t stream)
+template <typename T>
+static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &a, int nmodels, int max_nlayers, int grid_x,
+                                 hipStream_t stream)
 {
     using namespace rtmi;
-    const TraceArgs a = *args;
-    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(double);
+    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(T);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
     const bool want_ss = a.d_obs != nullptr;
     if (want_ss && want_t)
-        hipLaunchKernelGGL((trace_kernel<false, true, true>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((trace_kernel<T, false, true, true>), grid, block, lds_bytes, stream, a);
     else if (want_ss)
-        hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((trace_kernel<T, false, false, true>), grid, block, lds_bytes, stream, a);
     else if (want_p)
-        hipLaunchKernelGGL((trace_kernel<true, true, false>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((trace_kernel<T, true, true, false>), grid, block, lds_bytes, stream, a);
     else
-        hipLaunchKernelGGL((trace_kernel<false, true, false>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((trace_kernel<T, false, true, false>), grid, block, lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+extern "C" hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
+                                        hipStream_t stream)
+{
+    return launch_trace_t<double>(*args, nmodels, max_nlayers, grid_x, stream);
+}
+
+extern "C" hipError_t rtmi_launch_trace_f32(const rtmi::TraceArgsT<float> *args, int nmodels, int max_nlayers,
+                                            int grid_x, hipStream_t stream)
+{
+    return launch_trace_t<float>(*args, nmodels, max_nlayers, grid_x, stream);
 }
 
 extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, const double *d_sd, int64_t ndat,
@@ -572,8 +587,9 @@ extern "C" hipError_t rtmi_launch_loglike(const double *d_partial, int nparts, c
 // *slots = records per workgroup and round (multiple of 64), *lds_bytes per workgroup (table sized for
 // `max_nlayers`).
 extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd,
-                                   int *threads, int *slots, size_t *lds_bytes)
+                                   int elem_bytes, int *threads, int *slots, size_t *lds_bytes)
 {
+    const size_t slot_bytes = (size_t)3 * elem_bytes + 10;  // RTMI_SLOT_BYTES(T)
     const int64_t nchunks = (nsrc + 63) / 64;
     if (waves_per_simd < 1)
         waves_per_simd = 1;
@@ -591,10 +607,10 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(double);
+    const size_t table = ((size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * elem_bytes + 7) / 8 * 8;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 8;
     size_t share = (size_t)160 * 1024 / wg_per_cu;
-    int64_t max_slots = share > fixed + 64 * RTMI_SLOT_BYTES ? (int64_t)((share - fixed) / RTMI_SLOT_BYTES / 64 * 64) : 64;
+    int64_t max_slots = share > fixed + 64 * slot_bytes ? (int64_t)((share - fixed) / slot_bytes / 64 * 64) : 64;
     if (max_slots > 8128)
         max_slots = 8128;  // 13-bit local index
     int64_t want = chunks_per_block * 64;
@@ -602,43 +618,45 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
         want = max_slots;
     *threads = waves * 64;
     *slots = (int)want;
-    *lds_bytes = fixed + (size_t)want * RTMI_SLOT_BYTES;
+    *lds_bytes = fixed + (size_t)want * slot_bytes;
     return (int)nblocks;
 }
 
-template <bool P, bool T, bool S>
+template <typename T, bool P, bool WT, bool S>
 static hipError_t set_fused_lds_limit()
 {
     // dynamic LDS above 64 KiB needs the opt-in
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<P, T, S>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// args: d_vels/d_depths/(d_nlayers|nlayers)/ld_model, sources, outputs, refill_min, d_stamps filled by the
-// caller; slots is set here.  *grid_x_out (may be NULL) receives the workgroups per model (= partial sums per model).
-extern "C" hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
-                                        int waves_per_simd, int *grid_x_out, hipStream_t stream)
+// args: d_vels/d_depths/(d_nlayers|nlayers)/ld_model, sources, outputs, refill_min, tail_group, d_stamps filled by
+// the caller; slots is set here.  *grid_x_out (may be NULL) receives the workgroups per model (= partial sums per
+// model).
+template <typename T>
+static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, int max_nlayers, int num_cus,
+                                 int waves_per_simd, int *grid_x_out, hipStream_t stream)
 {
     using namespace rtmi;
-    static bool attr_set = false;
+    static bool attr_set = false;  // one flag per element type
     if (!attr_set) {
-        hipError_t e = set_fused_lds_limit<false, true, false>();
+        hipError_t e = set_fused_lds_limit<T, false, true, false>();
         if (e == hipSuccess)
-            e = set_fused_lds_limit<true, true, false>();
+            e = set_fused_lds_limit<T, true, true, false>();
         if (e == hipSuccess)
-            e = set_fused_lds_limit<false, true, true>();
+            e = set_fused_lds_limit<T, false, true, true>();
         if (e == hipSuccess)
-            e = set_fused_lds_limit<false, false, true>();
+            e = set_fused_lds_limit<T, false, false, true>();
         if (e != hipSuccess)
             return e;
         attr_set = true;
     }
-    FusedArgs a = *args;
+    FusedArgsT<T> a = args;
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
-    const int nblocks =
-        rtmi_fused_geometry(a.nsrc, max_nlayers, nmodels, num_cus, waves_per_simd, &threads, &a.slots, &lds_bytes);
+    const int nblocks = rtmi_fused_geometry(a.nsrc, max_nlayers, nmodels, num_cus, waves_per_simd, (int)sizeof(T),
+                                            &threads, &a.slots, &lds_bytes);
     if (grid_x_out)
         *grid_x_out = nblocks;
     if (lds_bytes > 160 * 1024)
@@ -648,14 +666,26 @@ extern "C" hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels
     const bool want_t = a.d_timeP != nullptr;
     const bool want_ss = a.d_obs != nullptr;
     if (want_ss && want_t)
-        hipLaunchKernelGGL((fused_kernel<false, true, true>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((fused_kernel<T, false, true, true>), grid, block, lds_bytes, stream, a);
     else if (want_ss)
-        hipLaunchKernelGGL((fused_kernel<false, false, true>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((fused_kernel<T, false, false, true>), grid, block, lds_bytes, stream, a);
     else if (want_p)
-        hipLaunchKernelGGL((fused_kernel<true, true, false>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((fused_kernel<T, true, true, false>), grid, block, lds_bytes, stream, a);
     else
-        hipLaunchKernelGGL((fused_kernel<false, true, false>), grid, block, lds_bytes, stream, a);
+        hipLaunchKernelGGL((fused_kernel<T, false, true, false>), grid, block, lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+extern "C" hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
+                                        int waves_per_simd, int *grid_x_out, hipStream_t stream)
+{
+    return launch_fused_t<double>(*args, nmodels, max_nlayers, num_cus, waves_per_simd, grid_x_out, stream);
+}
+
+extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers,
+                                            int num_cus, int waves_per_simd, int *grid_x_out, hipStream_t stream)
+{
+    return launch_fused_t<float>(*args, nmodels, max_nlayers, num_cus, waves_per_simd, grid_x_out, stream);
 }
 
 extern "C" hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den,

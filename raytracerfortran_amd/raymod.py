@@ -49,6 +49,7 @@ SIGNATURES = {
     "rtmi_device_cus": (ctypes.c_int, []),
     "rtmi_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    "rtmi_trace_device_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_batch_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64,
                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
@@ -249,14 +250,17 @@ def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, 
     n = int(src_offset.numel())
     if src_depth.numel() != n:
         raise ValueError("src_offset / src_depth size mismatch")
+    f64 = src_offset.dtype  # torch.float64 (the reference's precision) or torch.float32 (rtmi_trace_device_f32)
+    if f64 not in (torch.float64, torch.float32):
+        raise ValueError("src_offset must be float64 or float32")
     if timeP is None:
-        timeP = torch.empty(n, dtype=torch.float64, device=src_offset.device)
+        timeP = torch.empty(n, dtype=f64, device=src_offset.device)
     if timeP.numel() < n or (p_final is not None and p_final.numel() < n):
         raise ValueError("output too small")
-    f64 = torch.float64
-    _check(lib.rtmi_trace_device(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers,
-                                 _ptr(src_offset, f64, "src_offset"), _ptr(src_depth, f64, "src_depth"), n,
-                                 _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"), _stream_ptr(stream)))
+    fn = lib.rtmi_trace_device if f64 == torch.float64 else lib.rtmi_trace_device_f32
+    _check(fn(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers, _ptr(src_offset, f64, "src_offset"),
+              _ptr(src_depth, f64, "src_depth"), n, _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"),
+              _stream_ptr(stream)))
     return timeP
 
 

@@ -419,6 +419,44 @@ def test_loglhood_batch_host_entry(rt, O, kat):
         rt.loglhood_batch(V, D, np.array([8, 99], np.int32), np.array([0.02, 0.02]))
 
 
+def c5_workload(n, seed=2025):
+    """20 interfaces, 21 sorted velocities."""
+    rng = np.random.default_rng(seed)
+    d = np.cumsum(rng.uniform(200, 600, 20))
+    v = np.sort(rng.uniform(1500, 6500, 21))
+    return v, d, rng.uniform(10, 8000, n), rng.uniform(50, d[-1] + 500, n)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_fp32_path_config5(rt, O, path):
+    """BASELINE config 5 (fp32 kernel path, 20 interfaces): the single-precision kernels equal the oracle built in
+    single precision bit for bit (same operation order), and the deviation from the fp64 result is reported."""
+    import torch
+    n = 1_000_000 if path == 2 else 50_000
+    v, d, off, dep = c5_workload(n)
+    f32 = torch.float32
+    a = [torch.tensor(x.astype(np.float32), device="cuda") for x in (v, d, off, dep)]
+    p = torch.empty(n, dtype=f32, device="cuda")
+    try:
+        rt.set_option("path", path)
+        t32 = rt.trace_device(*a, p_final=p).cpu().numpy()
+    finally:
+        rt.set_option("path", 0)
+    assert t32.dtype == np.float32
+    ref32, pref, nl = O.oracle_dff_f32(v, d, off, dep, want_p=True)
+    assert np.array_equal(t32, ref32), f"{(t32 != ref32).sum()} of {n} differ from the fp32 oracle"
+    pp = p.cpu().numpy()
+    assert np.array_equal(pp[nl > 1], pref[nl > 1], equal_nan=True)
+    # delta-t vs fp64 on the same (float-rounded) inputs
+    t64 = O.oracle_dff(v.astype(np.float32), d.astype(np.float32), off.astype(np.float32), dep.astype(np.float32))
+    both = (t32 != -999.0) & (t64 != -999.0)
+    dt = np.abs(t32[both].astype(np.float64) - t64[both])
+    print(f"fp32 vs fp64, {n} sources x 20 interfaces: max |dt| = {dt.max():.3e} s, 99.9 pct = "
+          f"{np.quantile(dt, 0.999):.3e} s, median = {np.median(dt):.3e} s; -999: fp32 {int((t32 == -999).sum())}, "
+          f"fp64 {int((t64 == -999).sum())}")
+    assert np.median(dt) < 1e-5 and np.quantile(dt, 0.999) < 5e-2
+
+
 def test_many_layers(rt, O):
     """Up to the 1024-interface limit of the kernels (the reference's sampler copy stops at 99)."""
     rng = np.random.default_rng(8)

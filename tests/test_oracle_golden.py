@@ -121,3 +121,19 @@ def test_live_reference_random_models():
         r = O.ref_dff(v, d, off, dep)
         worst = max(worst, compare_times(t, r, tol=1e-12))
     assert worst == 0.0
+
+
+def test_fp32_oracle_tracks_fp64():
+    """The single-precision build of the restatement (checker of the fp32 kernel path, BASELINE config 5) follows
+    the double-precision one to single-precision accuracy on typical rays; the tail (near-critical rays, different
+    iteration paths through the |f| < 0.1 m exit) is reported by the GPU test."""
+    rng = np.random.default_rng(2025)
+    d = np.cumsum(rng.uniform(200, 600, 20))
+    v = np.sort(rng.uniform(1500, 6500, 21))
+    off, dep = rng.uniform(10, 8000, 20000), rng.uniform(50, d[-1] + 500, 20000)
+    t32 = O.oracle_dff_f32(v, d, off, dep)
+    t64 = O.oracle_dff(v.astype(np.float32), d.astype(np.float32), off.astype(np.float32), dep.astype(np.float32))
+    assert t32.dtype == np.float32
+    both = (t32 != -999.0) & (t64 != -999.0)
+    dt = np.abs(t32[both].astype(np.float64) - t64[both])
+    assert both.mean() > 0.99 and np.median(dt) < 1e-5
