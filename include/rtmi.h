@@ -169,7 +169,9 @@ int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc);
  * expansions minus their exponent-range handling when all operands of a wave are inside a guarded
  * range.  This compares those forms bit for bit with the plain operators on caller-
  * supplied operands: d_mismatch[0] += sqrt mismatches over d_w, d_mismatch[1] += divide mismatches
- * over (d_num, d_den).  d_mismatch (2 x uint64) must be zeroed by the caller.  All device pointers.
+ * over (d_num, d_den), d_mismatch[2] += mismatches of the shared-reciprocal layer term
+ * (num/sqrt(w) and den/sqrt(w)^3 against sqrt and two plain divides).  d_mismatch (3 x uint64) must be
+ * zeroed by the caller.  All device pointers.
  */
 int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double *d_den, int64_t n,
                            unsigned long long *d_mismatch, void *stream);

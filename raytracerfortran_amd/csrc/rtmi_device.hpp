@@ -182,6 +182,40 @@ __device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-9
     return __builtin_fma(res, r, q);
 }
 
+// One layer term of costFunc and costFunc_Prime with a shared reciprocal:  tf = a / s,  tp = hv / ((s*s)*s),
+// s = sqrt(w).  The square-root iteration already carries h ~ 1/(2s); 2h refined by one Newton step against
+// the final s is the (correctly rounded, Markstein 1990) reciprocal r of s, which serves the first quotient
+// directly and -- cubed, then refined once against the ROUNDED cube s3 the reference divides by -- the
+// second.  Each quotient ends with the same residual correction q' = fma(fma(-d, q, n), r, q) as the plain
+// divide, i.e. it is the correctly rounded n/d whenever r is accurate to about an ulp.  Two v_rcp_f64
+// (quarter rate) and four fma per term are saved against two independent divides.  Bitwise equality with
+// `sqrt` and `/` is checked on the GPU over 2^28 solver-shaped operands (test_fast_math_equals_ieee) and by
+// every parity test; the guards of eval_terms apply unchanged.
+__device__ __forceinline__ void term_guarded(double w, double a, double hv, double &tf, double &tp)
+{
+    const double y = __builtin_amdgcn_rsq(w);
+    double g = w * y;
+    double h = y * 0.5;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, w);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, w);
+    g = __builtin_fma(d, h, g);  // g = sqrt(w), as sqrt_guarded
+    double r = h + h;            // ~ 1/s
+    e = __builtin_fma(-g, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    tf = __builtin_fma(__builtin_fma(-g, q, a), r, q);
+    const double s3 = (g * g) * g;
+    double r3 = (r * r) * r;
+    e = __builtin_fma(-s3, r3, 1.0);
+    r3 = __builtin_fma(r3, e, r3);
+    const double q3 = hv * r3;
+    tp = __builtin_fma(__builtin_fma(-s3, q3, hv), r3, q3);
+}
+
 // costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
 // `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
@@ -199,9 +233,7 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
         T tf, tp;
         if constexpr (FAST && std::is_same<T, double>::value) {
             ok = ok && (w > 1e-60 || i >= nfull);
-            const double s = sqrt_guarded(w);
-            tf = div_guarded(hv * x, s);
-            tp = div_guarded(hv, (s * s) * s);
+            term_guarded(w, hv * x, hv, tf, tp);
         } else {
             const T s = sqrt(w);
             tf = (hv * x) / s;
@@ -216,9 +248,10 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
         const T w = T(1.0) - xx * vvl;
         if constexpr (FAST && std::is_same<T, double>::value) {
             ok = ok && (w > 1e-60);
-            const double s = sqrt_guarded(w);
-            sf = sf + div_guarded(hvl * x, s);
-            sp = sp + div_guarded(hvl, (s * s) * s);
+            double tf, tp;
+            term_guarded(w, hvl * x, hvl, tf, tp);
+            sf = sf + tf;
+            sp = sp + tp;
         } else {
             const T s = sqrt(w);
             sf = sf + (hvl * x) / s;

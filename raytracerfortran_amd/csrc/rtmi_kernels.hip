@@ -498,11 +498,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
 }
 
 // Diagnostic: bitwise comparison of the guarded sqrt/divide with the plain operators.
-// out[0] += sqrt mismatches over w[], out[1] += divide mismatches over (num[], den[]).
+// out[0] += sqrt mismatches over w[], out[1] += divide mismatches over (num[], den[]),
+// out[2] += mismatches of the shared-reciprocal layer term (w[], numerators num[] and den[]).
 __global__ void fastmath_check_kernel(const double *__restrict__ w, const double *__restrict__ num,
                                       const double *__restrict__ den, int64_t n, unsigned long long *out)
 {
-    unsigned long long bad_s = 0, bad_d = 0;
+    unsigned long long bad_s = 0, bad_d = 0, bad_t = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double a = sqrt_guarded(w[i]);
         const double b = sqrt(w[i]);
@@ -510,11 +511,20 @@ __global__ void fastmath_check_kernel(const double *__restrict__ w, const double
         const double c = div_guarded(num[i], den[i]);
         const double d = num[i] / den[i];
         bad_d += (__double_as_longlong(c) != __double_as_longlong(d));
+        // the shared-reciprocal layer term against sqrt and two plain divides (num[i] plays H*V*x, den[i] H*V)
+        double tf, tp;
+        term_guarded(w[i], num[i], den[i], tf, tp);
+        const double tf_ref = num[i] / b;
+        const double tp_ref = den[i] / ((b * b) * b);
+        bad_t += (__double_as_longlong(tf) != __double_as_longlong(tf_ref)) +
+                 (__double_as_longlong(tp) != __double_as_longlong(tp_ref));
     }
     if (bad_s)
         atomicAdd(&out[0], bad_s);
     if (bad_d)
         atomicAdd(&out[1], bad_d);
+    if (bad_t)
+        atomicAdd(&out[2], bad_t);
 }
 
 }  // namespace rtmi

@@ -302,16 +302,16 @@ def trace_batch_device(vels, depths, nlayers, src_offset, src_depth, timeP=None,
 
 
 def selftest_fastmath(w, num, den):
-    """(sqrt mismatches, divide mismatches) of the guarded fast forms vs the plain operators on the
-    given float64 CUDA tensors (rtmi_selftest_fastmath)."""
+    """(sqrt, divide, shared-reciprocal layer-term) mismatch counts of the guarded fast forms vs the plain
+    operators on the given float64 CUDA tensors (rtmi_selftest_fastmath)."""
     import torch
     lib = load_library()
     n = int(w.numel())
     if num.numel() != n or den.numel() != n:
         raise ValueError("size mismatch")
-    out = torch.zeros(2, dtype=torch.int64, device=w.device)
+    out = torch.zeros(3, dtype=torch.int64, device=w.device)
     f64 = torch.float64
     _check(lib.rtmi_selftest_fastmath(_ptr(w, f64, "w"), _ptr(num, f64, "num"), _ptr(den, f64, "den"), n,
                                       _ptr(out, torch.int64, "out"), _stream_ptr(None)))
     torch.cuda.synchronize()
-    return int(out[0]), int(out[1])
+    return int(out[0]), int(out[1]), int(out[2])

@@ -243,8 +243,8 @@ def test_fast_math_equals_ieee(rt):
     from raytracerfortran_amd import raymod
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 1 << 24
-    total_s = total_d = 0
-    for trial in range(4):
+    total_s = total_d = total_t = 0
+    for trial in range(6):
         u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         e = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if trial == 0:      # solver-like: w in (0, 1], numerators ~ H*V*p, denominators s and s^3
@@ -259,14 +259,26 @@ def test_fast_math_equals_ieee(rt):
             w = torch.exp(-138.0 * u)
             den = torch.exp(-207.0 * e)
             num = torch.exp(276.0 * (u - 0.5))
-        else:               # exact zeros and ones among ordinary values
+        elif trial == 3:    # exact zeros and ones among ordinary values
             w = torch.where(u < 0.1, torch.ones_like(u), u)
             den = torch.where(e < 0.1, torch.ones_like(e), e + 1e-3)
             num = torch.where(u > 0.9, torch.zeros_like(u), u - 0.5)
-        bs, bd = raymod.selftest_fastmath(w.contiguous(), num.contiguous(), den.contiguous())
+        elif trial == 4:    # the solver's own operands: w = 1 - p^2 v^2, numerators H V p and H V
+            pv = u * (1.0 - 1e-9)
+            w = 1.0 - pv * pv
+            hv = (50.0 + 3000.0 * e) * (1500.0 + 8500.0 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+            den = hv
+            num = hv * (pv / 6000.0)
+        else:               # near-critical layers: w down to 1e-12
+            w = torch.exp(-27.0 * u)
+            den = 1e5 + 1e7 * e
+            num = den * 1e-4 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        bs, bd, bt = raymod.selftest_fastmath(w.contiguous(), num.contiguous(), den.contiguous())
         total_s += bs
         total_d += bd
-    assert (total_s, total_d) == (0, 0)
+        if trial >= 3:      # the layer term is only ever fed solver-shaped operands (guards: w in (1e-60, 1])
+            total_t += bt
+    assert (total_s, total_d, total_t) == (0, 0, 0)
 
 
 def test_fused_kernel_many_layers_and_host_path(rt, O):
