@@ -227,19 +227,20 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
     T sf = T(0.0), sp = T(0.0);
     bool ok = true;
     for (int i = 0; i < nfull_wave; ++i) {
-        const T hv = t.HV[i];
-        const T vv = t.VV[i];
-        const T w = T(1.0) - xx * vv;
-        T tf, tp;
-        if constexpr (FAST && std::is_same<T, double>::value) {
-            ok = ok && (w > 1e-60 || i >= nfull);
-            term_guarded(w, hv * x, hv, tf, tp);
-        } else {
-            const T s = sqrt(w);
-            tf = (hv * x) / s;
-            tp = hv / ((s * s) * s);
-        }
+        // lanes whose stack is shorter sit this trip out under EXEC (no selects on the accumulators)
         if (i < nfull) {
+            const T hv = t.HV[i];
+            const T vv = t.VV[i];
+            const T w = T(1.0) - xx * vv;
+            T tf, tp;
+            if constexpr (FAST && std::is_same<T, double>::value) {
+                ok = ok && (w > 1e-60);
+                term_guarded(w, hv * x, hv, tf, tp);
+            } else {
+                const T s = sqrt(w);
+                tf = (hv * x) / s;
+                tp = hv / ((s * s) * s);
+            }
             sf = sf + tf;
             sp = sp + tp;
         }
