@@ -41,6 +41,8 @@ int fail(int code, const char *fmt, ...)
             return fail(RTMI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
     } while (0)
 
+#define RTMI_SMALL_CALL_NSRC 4096  // dff_ / TraceRays calls up to this size run on a mapped pinned buffer
+
 // Per-process context of the host-pointer entry points.
 struct Context {
     std::mutex mu;
@@ -62,6 +64,8 @@ struct Context {
     size_t lk_cap = 0;
     double *h_pin = nullptr;    // pinned staging of one batch (models in, logL/ss out)
     size_t pin_cap = 0;
+    double *h_small = nullptr;  // pinned, device-mapped buffer of the small-call path of dff_ / TraceRays
+    size_t small_cap = 0;
 };
 
 // Tuning knobs of the fused kernel, overridable from the environment for A/B runs.
@@ -175,6 +179,36 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
     HIP_TRY(hipSetDevice(c.device));
     const bool want_p = keep_delta > 0;
     const size_t n = (size_t)nsrc;
+    if (nsrc <= RTMI_SMALL_CALL_NSRC) {
+        // Small calls (the reference's own example has NSrc = 20): the kernel reads the model and the sources from,
+        // and writes the times to, ONE pinned host buffer mapped into the GPU's address space -- no copy commands,
+        // the call costs one launch and one stream synchronise.
+        const size_t nm = (size_t)2 * nlayers + 1;
+        const size_t need = nm + 4 * n;
+        if (c.small_cap < need) {
+            if (c.h_small)
+                HIP_TRY(hipHostFree(c.h_small));
+            c.h_small = nullptr;
+            c.small_cap = 0;
+            HIP_TRY(hipHostMalloc((void **)&c.h_small, (need + 1024) * sizeof(double), hipHostMallocMapped));
+            c.small_cap = need + 1024;
+        }
+        double *h = c.h_small, *dv = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dv, h, 0));
+        memcpy(h, vels, (size_t)(nlayers + 1) * sizeof(double));
+        memcpy(h + nlayers + 1, depths, (size_t)nlayers * sizeof(double));
+        memcpy(h + nm, src_offset, n * sizeof(double));
+        memcpy(h + nm + n, src_depth, n * sizeof(double));
+        rc = rtmi_trace_device(dv, dv + nlayers + 1, nlayers, dv + nm, dv + nm + n, nsrc, dv + nm + 2 * n,
+                               want_p ? dv + nm + 3 * n : nullptr, c.stream);
+        if (rc)
+            return rc;
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        memcpy(timeP, h + nm + 2 * n, n * sizeof(double));
+        if (want_p)
+            return rtmi_write_rays_dat("rays.dat", vels, depths, nlayers, src_offset, src_depth, h + nm + 3 * n, nsrc);
+        return RTMI_OK;
+    }
     rc = grow(&c.d_model, &c.model_cap, (size_t)2 * nlayers + 1);
     if (rc)
         return rc;
@@ -272,8 +306,10 @@ int rtmi_init(int device)
             (void)hipFree(c.d_lk);
         if (c.h_pin)
             (void)hipHostFree(c.h_pin);
-        c.d_set = c.d_lk = c.h_pin = nullptr;
-        c.set_cap = c.lk_cap = c.pin_cap = 0;
+        if (c.h_small)
+            (void)hipHostFree(c.h_small);
+        c.d_set = c.d_lk = c.h_pin = c.h_small = nullptr;
+        c.set_cap = c.lk_cap = c.pin_cap = c.small_cap = 0;
         c.set_n = 0;
         c.set_has_obs = false;
         if (c.stream)
