@@ -181,7 +181,7 @@ def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None,
 
 
 def bench_pt(args, rt, torch, dist, rank, world, dev):
-    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py): 32 chains per GPU over 1e4 shared sources
+    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, native sweep csrc/rtmi_pt.cpp): 32 chains per GPU over 1e4 shared sources
     (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
     logL all-gather over RCCL.  A "step" is one sweep of every chain; value = travel times traced per second."""
     from raytracerfortran_amd import tempering as T
@@ -197,7 +197,7 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                          torch.tensor(off, device=dev), torch.tensor(dep, device=dev)).cpu().numpy()
     ev = T.GpuEvaluator(off, dep, tt + rng.normal(0, 0.016, nsrc))
     nloc = 32
-    s = T.Sampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
+    s = T.NativeSampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
                   rank=rank, world=world, dist=dist if world > 1 else None,
                   dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)

@@ -90,6 +90,43 @@ int rtmi_set_sources(const double *src_offset, const double *src_depth, const do
 int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t *nlayers, int ld_model,
                         int nmodels, const double *sd, double *logL, double *ss);
 
+/*
+ * Native Metropolis-Hastings sweep of the reversible-jump sampler over the resident sources
+ * (rtmi_set_sources with observations first).  One handle = the tempered chains of one process; every
+ * proposal slot of a sweep -- birth/death, then each (node, parameter) perturbation -- is ONE
+ * rtmi_loglhood_batch launch for all chains, decisions are taken on the host:
+ *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
+ *   EXPLORE_MH           prjmh_temper_rf.f90:521-634   PROPOSAL_SDRT :1616   CHECKBOUNDS :1639
+ * for the reference configuration NPL = 2, ENOS = 0, IPOIPR = 1, ICOV = 1, I_VARPAR = 0.  Chain state: k
+ * nodes (depth, Vp), node 1 the surface node whose depth is not perturbed, and sigma.  The temperature
+ * exchange (TEMPSWP_MH :1329) is left to the caller, which owns the collective: it reads logL with
+ * rtmi_pt_get_chain and writes the new temperatures with rtmi_pt_set_beta.
+ */
+typedef struct rtmi_pt rtmi_pt;
+typedef struct {
+    int kmin, kmax;          /* NLMN, NLMX                                  read_input.f90:39-40  */
+    double lambda;           /* Poisson prior on k                          read_input.f90:78-81  */
+    double hmx, hmin;        /* max partition depth, min layer thickness    read_input.f90:46-47  */
+    double vmin, vmax;       /* Vp bounds (1500, 10000)                     read_input.f90:207-208 */
+    double sdmin, sdmax;     /* sigma bounds                                read_input.f90:234-236 */
+    double pertsdsc;         /* Cauchy step = (max - min) / pertsdsc (30)   read_input.f90:169,214 */
+    double pertsdsdsc;       /* sigma step = (sdmax - sdmin) / this (10)    read_input.f90:237-239 */
+} rtmi_pt_prior;
+/* ld_model >= kmax + 1; ndata = number of observations of the resident source set; (seed, stream_id)
+ * select the random streams (one per chain; use the rank as stream_id).  NULL on bad arguments. */
+rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_prior *prior, uint64_t seed,
+                        uint64_t stream_id);
+void rtmi_pt_destroy(rtmi_pt *h);
+int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const double *vels, double sd,
+                      double beta);
+int rtmi_pt_set_beta(rtmi_pt *h, const double *beta);
+int rtmi_pt_get_chain(const rtmi_pt *h, int chain, int *k, double *depths, double *vels, double *sd,
+                      double *logL, double *ss);
+int rtmi_pt_evaluate(rtmi_pt *h);             /* logL of the current states (after set_chain) */
+int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* nsweeps x (EXPLORE_MH_NOVARPAR + EXPLORE_MH) for every chain */
+/* out8: accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, launches, models */
+int rtmi_pt_stats(const rtmi_pt *h, int64_t *out8);
+
 /* ------------------------------------------------------------------------------------------
  * 2. Library state.
  * ------------------------------------------------------------------------------------------ */

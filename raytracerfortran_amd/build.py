@@ -17,9 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtmi.so")
 LIB7 = os.path.join(HERE, "librtmi_dff7.so")
-SOURCES = [os.path.join(CSRC, "rtmi_kernels.hip"), os.path.join(CSRC, "rtmi_capi.cpp")]
+SOURCES = [os.path.join(CSRC, "rtmi_kernels.hip"), os.path.join(CSRC, "rtmi_capi.cpp"),
+           os.path.join(CSRC, "rtmi_pt.cpp")]
 SHIM7 = os.path.join(CSRC, "rtmi_dff7_shim.c")
-HEADERS = [os.path.join(CSRC, "rtmi_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]
+HEADERS = [os.path.join(CSRC, "rtmi_kernels.h"), os.path.join(CSRC, "rtmi_device.hpp"), os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"

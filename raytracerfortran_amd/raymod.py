@@ -43,6 +43,14 @@ SIGNATURES = {
     "rtmi_set_sources": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int64]),
     "rtmi_loglhood_batch": (ctypes.c_int, [_dp, _dp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, _dp,
                                             _dp, _dp]),
+    "rtmi_pt_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_uint64, ctypes.c_uint64]),
+    "rtmi_pt_destroy": (None, [_vp]),
+    "rtmi_pt_set_chain": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]),
+    "rtmi_pt_set_beta": (ctypes.c_int, [_vp, _dp]),
+    "rtmi_pt_get_chain": (ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, _dp, _dp, _dp]),
+    "rtmi_pt_evaluate": (ctypes.c_int, [_vp]),
+    "rtmi_pt_sweep": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rtmi_pt_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_init": (ctypes.c_int, [ctypes.c_int]),
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
@@ -205,6 +213,76 @@ def loglhood_batch(vels, depths, nlayers, sd, want_ss: bool = False):
                                    nl.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ld, nm, sd.ctypes.data_as(_dp),
                                    logl.ctypes.data_as(_dp), ss.ctypes.data_as(_dp) if want_ss else None))
     return (logl, ss) if want_ss else logl
+
+
+class PtPrior(ctypes.Structure):
+    """rtmi_pt_prior of include/rtmi.h."""
+    _fields_ = [("kmin", ctypes.c_int), ("kmax", ctypes.c_int), ("lam", ctypes.c_double), ("hmx", ctypes.c_double),
+                ("hmin", ctypes.c_double), ("vmin", ctypes.c_double), ("vmax", ctypes.c_double),
+                ("sdmin", ctypes.c_double), ("sdmax", ctypes.c_double), ("pertsdsc", ctypes.c_double),
+                ("pertsdsdsc", ctypes.c_double)]
+
+
+class NativeChains:
+    """The chains of one process inside librtmi.so (rtmi_pt_*): native Metropolis-Hastings sweeps over the resident
+    sources (set_sources with observations first)."""
+
+    def __init__(self, nchains, ld, ndata, prior, seed=1, stream_id=0):
+        self.lib = load_library()
+        self.n, self.ld = int(nchains), int(ld)
+        pr = PtPrior(prior.kmin, prior.kmax, prior.lam, prior.hmx, prior.hmin, prior.vmin, prior.vmax, prior.sdmin,
+                     prior.sdmax, prior.pertsdsc, prior.pertsdsdsc)
+        self.h = self.lib.rtmi_pt_create(self.n, self.ld, int(ndata), ctypes.byref(pr), int(seed), int(stream_id))
+        if not self.h:
+            raise RtmiError("rtmi_pt_create: bad arguments")
+
+    def close(self):
+        if self.h:
+            self.lib.rtmi_pt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chain(self, i, nodes, sd, beta):
+        z, v = _as_f64(nodes[:, 0]), _as_f64(nodes[:, 1])
+        _check(self.lib.rtmi_pt_set_chain(self.h, i, z.size, z.ctypes.data_as(_dp), v.ctypes.data_as(_dp), float(sd),
+                                          float(beta)))
+
+    def set_beta(self, beta):
+        b = _as_f64(beta, self.n, "beta")
+        _check(self.lib.rtmi_pt_set_beta(self.h, b.ctypes.data_as(_dp)))
+
+    def get_chain(self, i):
+        k = ctypes.c_int()
+        z, v = np.empty(self.ld), np.empty(self.ld)
+        sd, ll, ss = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(self.lib.rtmi_pt_get_chain(self.h, i, ctypes.byref(k), z.ctypes.data_as(_dp), v.ctypes.data_as(_dp),
+                                          ctypes.byref(sd), ctypes.byref(ll), ctypes.byref(ss)))
+        return np.column_stack([z[:k.value], v[:k.value]]), sd.value, ll.value, ss.value
+
+    def logl(self):
+        ll = ctypes.c_double()
+        out = np.empty(self.n)
+        for i in range(self.n):
+            _check(self.lib.rtmi_pt_get_chain(self.h, i, None, None, None, None, ctypes.byref(ll), None))
+            out[i] = ll.value
+        return out
+
+    def evaluate(self):
+        _check(self.lib.rtmi_pt_evaluate(self.h))
+
+    def sweep(self, nsweeps=1):
+        _check(self.lib.rtmi_pt_sweep(self.h, int(nsweeps)))
+
+    def stats(self):
+        out = (ctypes.c_int64 * 8)()
+        _check(self.lib.rtmi_pt_stats(self.h, out))
+        names = ("acc_bd", "prop_bd", "acc_mh", "prop_mh", "acc_sd", "prop_sd", "launches", "models")
+        return dict(zip(names, [int(x) for x in out]))
 
 
 def write_rays_dat(path, vels, depths, src_offset, src_depth, p_final) -> None:

@@ -128,3 +128,55 @@ def test_tempered_run_on_test_1(kat):
         ref = O.oracle_loglhood_rt(obs, t, c.sd, stable=True)
         assert abs(c.logL - ref) <= 1e-9 * max(1.0, abs(ref))
     assert s.stats["acc_mh"] > 0 and s.stats["acc_swap"] > 0
+
+
+@pytest.mark.gpu
+def test_native_sweep_samples_the_prior_at_beta_zero(kat):
+    """rtmi_pt_sweep (csrc/rtmi_pt.cpp) with beta = 0: the likelihood drops out of every acceptance ratio, so k must
+    follow the truncated Poisson prior -- birth/death/bounds bookkeeping of the native sweep -- while every proposal
+    still goes through the GPU likelihood."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    rt.set_sources(kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"])
+    pr = T.Prior(kmin=1, kmax=6, lam=2.0, hmin=1e-6, hmx=10000.0)
+    nat = raymod.NativeChains(16, 32, 20, pr, seed=4, stream_id=0)
+    for i in range(16):
+        nat.set_chain(i, np.array([[0.0, 4000.0]]), 0.02, 0.0)
+    nat.evaluate()
+    nat.sweep(300)
+    ks = []
+    for it in range(1500):
+        nat.sweep(1)
+        ks += [nat.get_chain(i)[0].shape[0] for i in range(16)]
+    ks = np.array(ks)
+    w = np.array([math.exp(pr.log_pk(k)) for k in range(1, 7)])
+    w /= w.sum()
+    freq = np.array([(ks == k).mean() for k in range(1, 7)])
+    assert np.abs(freq - w).max() < 0.03, (freq, w)
+    st = nat.stats()
+    assert st["acc_bd"] > 0 and st["acc_mh"] > 0 and st["acc_sd"] > 0 and st["models"] > st["launches"] > 1500
+
+
+@pytest.mark.gpu
+def test_native_sampler_on_test_1(kat):
+    """NativeSampler (sweeps inside librtmi.so, swaps here) on the reference's test_1 problem: logL bookkeeping of
+    every chain equals the oracle, the T = 1 chain stays in the high-likelihood region, swaps happen."""
+    from oracle import oracle as O
+    m = kat["model"]
+    off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
+    ev = T.GpuEvaluator(off, dep, obs)
+    s = T.NativeSampler(T.Prior(), ev, ndata=20, nchains_total=8, nptchains1=1, dTlog=1.4, seed=2)
+    s.init_from_model(np.column_stack([[0.0] + m["depths"], m["vels"]]), 0.02)
+    assert abs(s.chains[0].logL - kat["test_1_map_logL_survey"]["value"]) < 1e-8
+    samples = s.run(600, burnin=100)
+    s.sync()
+    assert len(samples) == 500
+    ll = np.array([x[3] for x in samples])
+    assert ll.max() > 45.0 and np.median(ll) > 30.0
+    for c in s.chains:
+        v, z = T.layering(c.nodes)
+        t = O.oracle_dff(v, z, off, dep)
+        ref = O.oracle_loglhood_rt(obs, t, c.sd, stable=True)
+        assert abs(c.logL - ref) <= 1e-9 * max(1.0, abs(ref))
+        assert T.inside_bounds(c.nodes, s.prior)
+    assert s.stats["acc_mh"] > 0 and s.stats["acc_swap"] > 0 and s.stats["acc_bd"] >= 0
