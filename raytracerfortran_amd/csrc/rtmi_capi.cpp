@@ -119,6 +119,7 @@ int ensure_ready_locked(Context &c)
     HIP_TRY(hipGetDeviceProperties(&prop, c.device));
     c.cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(rtmi_prepare_kernels());
     c.ready = true;
     return RTMI_OK;
 }

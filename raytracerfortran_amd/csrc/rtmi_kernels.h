@@ -57,6 +57,7 @@ typedef FusedArgsT<double> FusedArgs;
 }  // namespace rtmi
 
 extern "C" {
+hipError_t rtmi_prepare_kernels();
 int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd, int elem_bytes,
                         int *threads, int *slots, size_t *lds_bytes);
 hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers, int num_cus,

@@ -644,22 +644,42 @@ static hipError_t set_fused_lds_limit()
 // the caller; slots is set here.  *grid_x_out (may be NULL) receives the workgroups per model (= partial sums per
 // model).
 template <typename T>
+static hipError_t prepare_fused_t()
+{
+    static bool attr_set = false;  // one flag per element type
+    if (attr_set)
+        return hipSuccess;
+    hipError_t e = set_fused_lds_limit<T, false, true, false>();
+    if (e == hipSuccess)
+        e = set_fused_lds_limit<T, true, true, false>();
+    if (e == hipSuccess)
+        e = set_fused_lds_limit<T, false, true, true>();
+    if (e == hipSuccess)
+        e = set_fused_lds_limit<T, false, false, true>();
+    if (e == hipSuccess)
+        attr_set = true;
+    return e;
+}
+
+// One-time function attributes (not stream operations): done at context creation so that the launchers stay
+// graph-capturable from the first call.
+extern "C" hipError_t rtmi_prepare_kernels()
+{
+    hipError_t e = prepare_fused_t<double>();
+    if (e == hipSuccess)
+        e = prepare_fused_t<float>();
+    return e;
+}
+
+template <typename T>
 static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, int max_nlayers, int num_cus,
                                  int waves_per_simd, int *grid_x_out, hipStream_t stream)
 {
     using namespace rtmi;
-    static bool attr_set = false;  // one flag per element type
-    if (!attr_set) {
-        hipError_t e = set_fused_lds_limit<T, false, true, false>();
-        if (e == hipSuccess)
-            e = set_fused_lds_limit<T, true, true, false>();
-        if (e == hipSuccess)
-            e = set_fused_lds_limit<T, false, true, true>();
-        if (e == hipSuccess)
-            e = set_fused_lds_limit<T, false, false, true>();
+    {
+        const hipError_t e = prepare_fused_t<T>();  // no-op after rtmi_init / the first call
         if (e != hipSuccess)
             return e;
-        attr_set = true;
     }
     FusedArgsT<T> a = args;
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);

@@ -469,6 +469,27 @@ def test_fp32_path_config5(rt, O, path):
     assert np.median(dt) < 1e-5 and np.quantile(dt, 0.999) < 5e-2
 
 
+def test_device_entry_points_are_graph_capturable(rt, O):
+    """rtmi_trace_device / rtmi_trace_batch_device allocate nothing and never synchronise: a HIP graph captured
+    around them replays to the same bits (launch-bound inner loops of a sampler can be replayed as graphs)."""
+    import torch
+    n = 200_000
+    v, d, off, dep = c2_workload(n, seed=9)
+    dv, dd, do, dz = (torch.tensor(x, device="cuda") for x in (v, d, off, dep))
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    rt.trace_device(dv, dd, do, dz, timeP=out)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rt.trace_device(dv, dd, do, dz, timeP=out)
+    out.zero_()
+    do.copy_(torch.tensor(off[::-1].copy(), device="cuda"))  # new inputs in the captured buffers
+    dz.copy_(torch.tensor(dep[::-1].copy(), device="cuda"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.oracle_dff(v, d, off[::-1], dep[::-1]))
+
+
 def test_many_layers(rt, O):
     """Up to the 1024-interface limit of the kernels (the reference's sampler copy stops at 99)."""
     rng = np.random.default_rng(8)
