@@ -19,21 +19,28 @@
 //      batch (grid.y = model).  Its cost is set by the slowest lane of each wave: deepest source x
 //      most evaluations, i.e. ~20 % of the executed lane-instructions are useful on random input.
 //
-//  (2) fused_kernel -- the large-NSrc path, same arithmetic per source, scheduled so that lanes
-//      stay busy.  Each wave owns an interleaved set of 64-source chunks and keeps their records in
-//      LDS:
-//        a. load: coalesced reads of offset/depth, whichLayer, start value p0, and a wave-local
-//           counting sort of the records by DESCENDING layer index (LDS atomics, 64 bins), so that
-//           the layer loop of the wave has one trip count at any time; straight top-layer rays are
-//           finished here;
-//        b. solve: a lane that finishes its source takes the next record of the wave's queue
-//           (lane refill, once `refill_min` lanes are idle), so the evaluation loop runs with
-//           nearly all 64 lanes active instead of waiting for the slowest source; no global memory
-//           traffic inside the loop (records and results live in LDS);
-//        c. time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written
-//           to timeP (the only HBM write).
-//      HBM traffic stays at the algorithmic 24 B per source (offset/depth are read a second time
-//      from L2 in the sort's second pass); no workspace, no global atomics, deterministic.
+//  (2) fused_kernel -- the large-NSrc path (and batches of models), same arithmetic per source, scheduled
+//      so that lanes stay busy.  One persistent workgroup per CU; workgroup b owns the 64-source chunks
+//      b, b + gridDim.x, ... and keeps their records in LDS, round by round:
+//        a.  load: coalesced reads of offset/depth, whichLayer, start value p0, and a STABLE counting
+//            sort of the records in LDS by DESCENDING layer index (ballots, no atomics: slots are the
+//            same on every run), so that a wave's layer loop has one trip count at any time; straight
+//            top-layer rays are finished here;
+//        a2. first evaluation of every record at full occupancy: GetPTime's branch (:136-153), which
+//            also splits the records into a long class (bisection first) and a short class (Newton
+//            from p0); sources converged at p0 are done;
+//        b.  solve: every wave pulls records from the workgroup's queue (long class first); a lane that
+//            finishes takes the next record once `refill_min` lanes are idle, so the evaluation loop
+//            runs with most lanes live instead of waiting for the slowest source; near the end of the
+//            queue the last records go to the first wave groups only (`tail_group`); no global
+//            memory traffic inside the loop (records and results live in LDS);
+//        c.  time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written to
+//            timeP (the only HBM write); with observations the squared residuals are reduced per
+//            workgroup in a fixed order (deterministic logL).
+//      HBM traffic stays at the algorithmic 24 B per source (offset/depth are read a second time from
+//      L2 in the sort's second pass); no workspace, no global atomics.
+//  Both kernels are templates on the scalar type: double is the reference's precision, float the
+//  fp32 path of BASELINE config 5 (no guarded fast path there: plain IEEE sqrtf and divide).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
