@@ -72,3 +72,28 @@ contains
    end subroutine dofullforwardproblem
 
 end module raymod
+
+
+!  Optional extension for samplers that want the whole likelihood on the GPU: the source set is uploaded once
+!  (what READDATA reads, read_input.f90:302-387) and LOGLHOOD is then evaluated for a batch of models in one launch
+!  (loglhood.f90:35-207).  Interfaces to include/rtmi.h; arrays are column-major on the Fortran side, so a model
+!  is a COLUMN of vels / depths: vels(ld_model, nmodels), depths(ld_model, nmodels).
+module rtmi_likelihood
+   use, intrinsic :: iso_c_binding, only : c_double, c_int, c_int32_t, c_int64_t
+   implicit none
+   interface
+      integer(c_int) function rtmi_set_sources(src_offset, src_depth, obs, nsrc) bind(C, name="rtmi_set_sources")
+         import :: c_double, c_int, c_int64_t
+         real(c_double), intent(in) :: src_offset(*), src_depth(*), obs(*)
+         integer(c_int64_t), value :: nsrc
+      end function rtmi_set_sources
+      integer(c_int) function rtmi_loglhood_batch(vels, depths, nlayers, ld_model, nmodels, sd, logL, ss) &
+            bind(C, name="rtmi_loglhood_batch")
+         import :: c_double, c_int, c_int32_t
+         real(c_double), intent(in) :: vels(*), depths(*), sd(*)
+         integer(c_int32_t), intent(in) :: nlayers(*)
+         integer(c_int), value :: ld_model, nmodels
+         real(c_double), intent(out) :: logL(*), ss(*)
+      end function rtmi_loglhood_batch
+   end interface
+end module rtmi_likelihood

@@ -22,5 +22,11 @@ def test_fortran_tracerays_caller(kat):
              " ".join(repr(x) for x in m["depths"])] + [f"{o!r} {z!r}" for o, z in zip(off, dep)]
     p = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
-    t = np.array([float(x) for x in p.stdout.split()])
+    lines_out = p.stdout.strip().splitlines()
+    t = np.array([float(x) for ln in lines_out if not ln.startswith("LOGL") for x in ln.split()])
     assert compare_times(t, kat["config1_ref_timeP"], 1e-9) == 0.0
+    # module rtmi_likelihood: rtmi_set_sources + rtmi_loglhood_batch from Fortran (obs = predictions -> SS = 0)
+    tag, rc, logl, ss = [ln for ln in lines_out if ln.startswith("LOGL")][0].split()
+    n = len(off)
+    assert int(rc) == 0 and float(ss) == 0.0
+    assert abs(float(logl) - (-0.5 * n * np.log(2 * np.pi) - n * np.log(0.02))) < 1e-10

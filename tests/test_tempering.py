@@ -180,3 +180,51 @@ def test_native_sampler_on_test_1(kat):
         assert abs(c.logL - ref) <= 1e-9 * max(1.0, abs(ref))
         assert T.inside_bounds(c.nodes, s.prior)
     assert s.stats["acc_mh"] > 0 and s.stats["acc_swap"] > 0 and s.stats["acc_bd"] >= 0
+
+
+def _native_pt_worker(rank, world, port, q, off, dep, obs, nodes):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import tempering as TT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt.init(0)  # both ranks rehearse on the one GPU of the box; on a node each rank has its own
+    ev = TT.GpuEvaluator(off, dep, obs)
+    s = TT.NativeSampler(TT.Prior(), ev, ndata=len(obs), nchains_total=8, nptchains1=2, dTlog=1.3, seed=5,
+                         rank=rank, world=world, dist=dist, dist_device="cpu")
+    s.init_from_model(np.array(nodes), 0.02)
+    samples = s.run(200, burnin=50)
+    s.sync()
+    q.put((rank, s.level.tolist(), s.stats["acc_swap"], len(samples), [float(c.logL) for c in s.chains],
+           [c.nodes.tolist() for c in s.chains], [c.sd for c in s.chains]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_chains_sharded_over_two_ranks_native(kat):
+    """BASELINE config 4's structure in miniature: 8 tempered chains sharded over 2 ranks (here both on the one
+    GPU of the box, all-gather over gloo; on a node one rank per GPU over RCCL), native sweeps, temperature swaps
+    decided identically on both ranks, every chain's logL equal to the oracle's for its final state."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    m = kat["model"]
+    off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
+    nodes = np.column_stack([[0.0] + m["depths"], m["vels"]]).tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_native_pt_worker, args=(r, 2, port, q, off, dep, obs, nodes)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, lev0, sw0, n0, ll0, nd0, sd0), (_, lev1, sw1, n1, ll1, nd1, sd1) = res
+    assert lev0 == lev1 and sorted(lev0) == [0, 0, 1, 2, 3, 4, 5, 6] and sw0 == sw1 > 0
+    assert n0 + n1 == 2 * 150
+    for ll, nd, sd in zip(ll0 + ll1, nd0 + nd1, sd0 + sd1):
+        v, z = T.layering(np.array(nd))
+        ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v, z, off, dep), sd, stable=True)
+        assert abs(ll - ref) <= 1e-9 * max(1.0, abs(ref))
