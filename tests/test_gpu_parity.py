@@ -235,6 +235,28 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail):
     assert np.array_equal(p1[good], p2[good])
 
 
+def test_fused_kernel_degenerate_rounds(rt, O):
+    """Rounds with nothing to solve (every source a straight top-layer ray), only hopeless data (NaN), every source
+    finished by its first evaluation, and a one-interface model -- through the fused kernel."""
+    import torch
+    v, d, off, dep = c2_workload(20000, seed=4)
+    cases = {"all straight": (off, np.full_like(dep, 0.5 * d[0])),
+             "all NaN": (np.full_like(off, np.nan), dep),
+             "zero offset": (np.zeros_like(off), dep)}
+    try:
+        rt.set_option("path", 2)
+        for name, (o, z) in cases.items():
+            t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
+                                torch.tensor(o, device="cuda"), torch.tensor(z, device="cuda")).cpu().numpy()
+            assert np.array_equal(t, O.oracle_dff(v, d, o, z), equal_nan=True), name
+        v1, d1 = np.array([3000.0, 5000.0]), np.array([1000.0])
+        t = rt.trace_device(torch.tensor(v1, device="cuda"), torch.tensor(d1, device="cuda"),
+                            torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
+        assert np.array_equal(t, O.oracle_dff(v1, d1, off, dep))
+    finally:
+        rt.set_option("path", 0)
+
+
 def test_fast_math_equals_ieee(rt):
     """The guarded sqrt / divide (compiler expansions without their exponent-range wrappers) return the same
     bits as the plain operators over the guarded operand ranges: random operands, operands shaped like the
