@@ -51,6 +51,16 @@ def read_parameter_file(path: str) -> Dict[str, object]:
     return out
 
 
+def write_parameter_file(path: str, par: Dict[str, object]) -> None:
+    """makeParameterFile's job (MiscFunctions.R:68-103): one "value ! NAME" record per parameter, in READPARFILE's order."""
+    with open(path, "w") as f:
+        for name in PARAMETER_NAMES:
+            v = par[name]
+            txt = " ".join(repr(float(x)) for x in v) if isinstance(v, (list, tuple)) else (
+                repr(float(v)) if name in _FLOAT_FIELDS else str(int(v)))
+            f.write(f" {txt} ! {name}\n")
+
+
 def read_map_file(path: str, nlmx: int, npl: int = 2, nmode: int = 1) -> Tuple[int, np.ndarray, float]:
     """(k, nodes[k, 2] = (depth, Vp), sigma) from the start-model row (prjmh_temper_rf.f90:152-189)."""
     tok = np.array(open(path).read().split(), dtype=float)

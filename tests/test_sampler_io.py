@@ -1,7 +1,7 @@
-"""The reference sampler's file formats (raytracerfortran_amd/sampler_io.py) on copies of the reference's own test_1
-inputs (tests/golden/test_1/: data files of the reference's example, unmodified)."""
+"""The reference sampler's file formats (raytracerfortran_amd/sampler_io.py) on the reference's test_1 problem: the
+directory is rebuilt from the values of tests/golden/kat_author.json (sources, observations, model) and the settings of
+/root/reference/test_1/test_1_parameter.dat, written through the module's own writers."""
 import os
-import shutil
 
 import numpy as np
 import pytest
@@ -9,10 +9,29 @@ import pytest
 from conftest import GOLDEN
 from raytracerfortran_amd import sampler_io as S
 
-T1 = os.path.join(GOLDEN, "test_1")
+# /root/reference/test_1/test_1_parameter.dat, value by value (read_input.f90:22-54 order)
+TEST_1_PARAMETERS = {"IMAP": 0, "ICOV": 1, "ENOS": 0, "IPOIPR": 1, "IAR": 0, "NPL": 2, "I_VARPAR": 0, "IBD_SINGLE": 0,
+                     "I_RT": 1, "I_VREF": 0, "I_VPVS": 0, "ISMPPRIOR": 0, "ISETSEED": 0, "IEXCHANGE": 1, "NDAT_RT": 20,
+                     "NMODE": 1, "NSRC": 20, "NLMN": 1, "NLMX": 10, "ICHAINTHIN": 5, "NKEEP": 100, "NPTCHAINS1": 1,
+                     "dTlog": 1.4, "lambda": 3.01, "hmx": 10000.1, "hmin": 100.1, "TCHCKPT": 1000.0, "dVs": 0.1,
+                     "dVpVs": 0.1, "sdmn": [0.001, 0.001], "sdmx": [0.07, 0.07], "VpVsmin": 1.5, "VpVsmax": 1.8}
 
 
-def test_parameter_and_map_files(kat):
+@pytest.fixture()
+def T1(tmp_path, kat):
+    """A test_1 directory as the reference's sampler expects it (filebase.txt + <base>_*.dat/.txt)."""
+    d = tmp_path / "test_1"
+    d.mkdir()
+    (d / "filebase.txt").write_text("6\ntest_1\n")
+    S.write_parameter_file(str(d / "test_1_parameter.dat"), TEST_1_PARAMETERS)
+    m = kat["model"]
+    S.write_map_file(str(d / "test_1_map.dat"), np.column_stack([[0.0] + m["depths"], m["vels"]]), 0.02, nlmx=10)
+    np.savetxt(d / "test_1_RT.txt", np.array(kat["test_1_obs_RT"]), fmt="%.17g")
+    np.savetxt(d / "test_1_src_data.txt", np.column_stack([kat["test_1_src_offset"], kat["test_1_src_depth"]]), fmt="%.17g")
+    return str(d)
+
+
+def test_parameter_and_map_files(kat, T1):
     assert S.read_filebase(T1) == "test_1"
     p = S.read_parameter_file(os.path.join(T1, "test_1_parameter.dat"))
     assert (p["IMAP"], p["NPL"], p["NDAT_RT"], p["NSRC"], p["NLMN"], p["NLMX"], p["ICHAINTHIN"], p["NKEEP"]) == \
@@ -26,6 +45,20 @@ def test_parameter_and_map_files(kat):
     obs, off, dep = S.read_data(os.path.join(T1, "test_1"), 20, 20)
     assert np.array_equal(obs, kat["test_1_obs_RT"]) and np.array_equal(off, kat["test_1_src_offset"])
     assert np.array_equal(dep, kat["test_1_src_depth"])
+
+
+def test_parameter_file_in_the_reference_layout(tmp_path):
+    """The reference's files carry "value ! NAME !! free comment" records, two values on the sdmn / sdmx lines and no
+    newline at the end (test_1_parameter.dat): list-directed READ semantics."""
+    lines = []
+    for name in S.PARAMETER_NAMES:
+        v = TEST_1_PARAMETERS[name]
+        txt = " ".join(str(x) for x in v) if isinstance(v, list) else str(v)
+        lines.append(f" {txt}   ! {name:10s} !! some comment, with commas and 1.5 numbers")
+    path = tmp_path / "x_parameter.dat"
+    path.write_text("\n".join(lines))  # no trailing newline
+    p = S.read_parameter_file(str(path))
+    assert p == TEST_1_PARAMETERS
 
 
 def test_map_file_round_trip(tmp_path):
@@ -53,7 +86,7 @@ class _Flat:
         return np.full(len(node_sets), 0.004)
 
 
-def test_run_from_files_with_injected_likelihood(tmp_path):
+def test_run_from_files_with_injected_likelihood(tmp_path, T1):
     """The file plumbing end to end on CPU (constant likelihood): samples land in <base>_voro_sample.txt."""
     r = S.run_from_files(T1, nsweeps=60, nchains=4, seed=3, out_dir=str(tmp_path), evaluator=_Flat())
     rows = S.read_sample_file(str(tmp_path / "test_1_voro_sample.txt"), 10)
@@ -62,22 +95,17 @@ def test_run_from_files_with_injected_likelihood(tmp_path):
 
 
 @pytest.mark.gpu
-def test_imap_mode_and_sampling_from_reference_files(tmp_path, kat):
+def test_imap_mode_and_sampling_from_reference_files(tmp_path, kat, T1):
     """IMAP = 1 (prjmh_temper_rf.f90:246-268): evaluate the MAP model of test_1 and write the replica files; then a
     short tempered run from the same files."""
-    d = tmp_path / "run"
-    d.mkdir()
-    for f in os.listdir(T1):  # plain copies: the snapshot's files may be read-only
-        shutil.copyfile(os.path.join(T1, f), d / f)
-    par = (d / "test_1_parameter.dat").read_text().splitlines()
-    par[0] = " 1   ! IMAP"
-    (d / "test_1_parameter.dat").write_text("\n".join(par) + "\n")
+    import pathlib
+    d = pathlib.Path(T1)
+    S.write_parameter_file(str(d / "test_1_parameter.dat"), dict(TEST_1_PARAMETERS, IMAP=1))
     r = S.run_from_files(str(d), 0)
     assert abs(r["logL"] - kat["test_1_map_logL_survey"]["value"]) < 1e-8
     pred = np.array((d / "test_1_mappredRT.dat").read_text().split(), dtype=float)
     assert np.abs(pred - np.array(kat["config1_ref_timeP"])).max() < 1e-10  # ES20.10 rounding
-    par[0] = " 0   ! IMAP"
-    (d / "test_1_parameter.dat").write_text("\n".join(par) + "\n")
+    S.write_parameter_file(str(d / "test_1_parameter.dat"), TEST_1_PARAMETERS)
     r = S.run_from_files(str(d), 100, nchains=4)
     rows = S.read_sample_file(str(d / "test_1_voro_sample.txt"), 10)
     assert len(rows) == 20 and max(x["logL"] for x in rows) > 40.0
