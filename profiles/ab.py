@@ -12,8 +12,7 @@ v, d, off, dep = bench.c2_workload(1_000_000)
 dev = "cuda"
 dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
 out = torch.empty(off.size, dtype=torch.float64, device=dev)
-settings = [dict(zip(("path", "waves_per_simd", "refill_min", "tail_group"), s)) for s in
-            [(2, w, m, t) for w in (4,) for m in (12, 16, 24) for t in (0, 384, 512, 768, 1024, 1536)]]
+settings = [dict(path=2, waves_per_simd=4, refill_min=m, tail_group=t, retire_max=r) for m in (16,) for t in (0, 512) for r in (0, 8, 16, 21)]
 ROUNDS, STEPS = 7, 10
 res = {i: [] for i in range(len(settings))}
 for r in range(ROUNDS):

@@ -74,13 +74,14 @@ struct Tuning {
     int solve_waves;     // resident waves per SIMD of the fused kernel
     int refill_min;      // idle lanes that trigger a refill
     int tail_group;      // end-game concentration (records per wave group), 0 = off
+    int retire_max;      // drain: live lanes a retiring wave hands over (0 = off)
     unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
 };
 
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, 512, nullptr};
+        Tuning v{0, 4, 16, 512, 8, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -93,6 +94,8 @@ Tuning &tuning()
             v.refill_min = atoi(e) > 0 ? atoi(e) : v.refill_min;
         if (const char *e = getenv("RTMI_TAIL_GROUP"))
             v.tail_group = atoi(e) >= 0 ? atoi(e) : v.tail_group;
+        if (const char *e = getenv("RTMI_RETIRE_MAX"))
+            v.retire_max = (atoi(e) >= 0 && atoi(e) <= 21) ? atoi(e) : v.retire_max;
         return v;
     }();
     return t;
@@ -342,6 +345,10 @@ int rtmi_set_option(const char *name, int value)
         if (value < 1 || value > 64)
             return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
         t.refill_min = value;
+    } else if (!strcmp(name, "retire_max")) {
+        if (value < 0 || value > 21)
+            return fail(RTMI_ERR_BAD_ARG, "retire_max must be in [0, 21]");
+        t.retire_max = value;
     } else if (!strcmp(name, "tail_group")) {
         if (value < 0 || value > 4096)
             return fail(RTMI_ERR_BAD_ARG, "tail_group must be in [0, 4096]");
@@ -389,6 +396,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.nlayers = nlayers;
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
+        fa.retire_max = tn.retire_max;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -508,6 +516,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.ld_model = ld_model;
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
+        fa.retire_max = tn.retire_max;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
         fa.nsrc = c.set_n;
@@ -560,6 +569,7 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.nlayers = nlayers;
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
+        fa.retire_max = tn.retire_max;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -642,6 +652,7 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.ld_model = ld_model;
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
+        fa.retire_max = tn.retire_max;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;

@@ -8,6 +8,7 @@
 #define RTMI_BLOCK 256          // threads per workgroup (4 waves: one per SIMD of a CU)
 #define RTMI_BLOCKS_PER_CU 16   // grid cap = CUs x this; further tiles are grid-strided
 #define RTMI_STAMPS_PER_WG 100  // diagnostic words per workgroup: 4 phase clocks + 6 per wave
+#define RTMI_POOL 256  // suspended lane states a workgroup can hand over in the drain (>= 12 waves x 16 + slack)
 #define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
 
 namespace rtmi {
@@ -43,6 +44,7 @@ struct FusedArgsT {
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
+    int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off, <= 21)
     const T *d_src_offset;  // [nsrc]
     const T *d_src_depth;   // [nsrc]
     int64_t nsrc;

@@ -203,6 +203,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     uint32_t *hist = tnl + slots;                             // [16 waves][64 bins] counts, then first slots
     uint32_t *qctl = hist + 16 * 64;                          // [0] queue head, [1] records sorted, [2] long, [3] short
     uint16_t *order = reinterpret_cast<uint16_t *>(qctl + 4); // solve order: slots of the long class, then the short
+    // hand-over pool of the drain (see "wave retirement" below): RTMI_POOL suspended lane states
+    T *pl_xe = reinterpret_cast<T *>(reinterpret_cast<char *>(order) + (((size_t)slots * sizeof(uint16_t) + 7) / 8) * 8);
+    T *pl_x = pl_xe + RTMI_POOL;
+    T *pl_xb = pl_x + RTMI_POOL;
+    T *pl_dx = pl_xb + RTMI_POOL;
+    int *pl_slot = reinterpret_cast<int *>(pl_dx + RTMI_POOL);
+    int *pl_state = pl_slot + RTMI_POOL;                        // st | k << 8 | conv << 16
+    volatile int *pl_ready = pl_state + RTMI_POOL;
+    volatile int *pl_ctl = pl_ready + RTMI_POOL;                // [0] head, [1] tail, [2] retirable waves still solving
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -268,7 +277,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 qctl[1] = total;
                 qctl[2] = 0;
                 qctl[3] = 0;
+                pl_ctl[0] = 0;
+                pl_ctl[1] = 0;
+                pl_ctl[2] = nwib > 4 ? nwib - 4 : 0;
             }
+            for (int i = lane; i < RTMI_POOL; i += 64)
+                pl_ready[i] = 0;
         }
         __syncthreads();
         uint32_t woff = hist[wib * 64 + lane];  // lane b: next free slot of bin b for this wave
@@ -375,6 +389,14 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         int slot = 0;
         bool exhausted = false;  // wave-uniform: the queue head has passed n_todo
         const int tail_group = a.tail_group < n_todo / 6 ? a.tail_group : n_todo / 6;  // short rounds: keep every wave fed
+        // Wave retirement (the drain): once the queue is empty the live lanes of every wave thin out, and sixteen
+        // waves at a few lanes each cost sixteen waves' worth of issue slots per trip.  Waves 4.. therefore hand
+        // their last `retire_max` live lane states over (LDS pool) and leave; waves 0..3 -- one per SIMD -- adopt
+        // them into their idle lanes and finish them with the SIMD to themselves.
+        const bool retirable = a.retire_max > 0 && nwib > 4 && wib >= 4;
+        const bool adopter = a.retire_max > 0 && nwib > 4 && wib < 4;
+        bool left = false;  // (retirable) this wave has signed off from pl_ctl[2]
+        int spins = 0;
         int nfull_wave = 0;
         // diagnostic occupancy counters (only touched when stamps are requested)
         unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0;
@@ -417,9 +439,85 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     }
                 }
                 nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
+            } else if (exhausted && retirable && !left && nidle < 64 && 64 - nidle <= a.retire_max) {
+                // hand the live lanes over and leave
+                const unsigned long long livem = ~idle;
+                const int nlive = 64 - nidle;
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd((int *)&pl_ctl[1], nlive);
+                base = __shfl(base, 0, 64);
+                if (s.st != ST_DONE) {
+                    const int e = base + __popcll(livem & lt_mask);  // < RTMI_POOL: at most 12 waves x retire_max
+                    pl_xe[e] = s.xe;
+                    pl_x[e] = s.x;
+                    pl_xb[e] = s.xb;
+                    pl_dx[e] = s.dx;
+                    pl_slot[e] = slot;
+                    pl_state[e] = s.st | (s.k << 8) | (s.conv ? 1 << 16 : 0);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    pl_ready[e] = 1;
+                    s.st = ST_DONE;
+                }
+            } else if (exhausted && adopter && nidle > 0) {
+                // adopt suspended lane states into the idle lanes
+                int base = 0, take = 0;
+                if (lane == 0) {
+                    int head = pl_ctl[0];
+                    for (;;) {
+                        const int avail = pl_ctl[1] - head;
+                        take = avail < nidle ? avail : nidle;
+                        if (take <= 0) {
+                            take = 0;
+                            break;
+                        }
+                        const int prev = atomicCAS((int *)&pl_ctl[0], head, head + take);
+                        if (prev == head)
+                            break;
+                        head = prev;
+                    }
+                    base = head;
+                }
+                base = __shfl(base, 0, 64);
+                take = __shfl(take, 0, 64);
+                if (take > 0) {
+                    const int r = __popcll(idle & lt_mask);
+                    if (s.st == ST_DONE && r < take) {
+                        const int e = base + r;
+                        int guard = 0;
+                        while (pl_ready[e] == 0 && ++guard < (1 << 22))
+                            __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        slot = pl_slot[e];
+                        const uint32_t key = rk[slot];
+                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                        lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
+                        const int ps = pl_state[e];
+                        s.xe = pl_xe[e];
+                        s.x = pl_x[e];
+                        s.xb = pl_xb[e];
+                        s.dx = pl_dx[e];
+                        s.st = ps & 0xFF;
+                        s.k = (ps >> 8) & 0xFF;
+                        s.conv = (ps >> 16) & 1;
+                    }
+                    nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
+                }
             }
             if (__all(s.st == ST_DONE)) {
-                if (exhausted) {
+                bool finished = exhausted;
+                if (exhausted && retirable && !left) {
+                    if (lane == 0)
+                        atomicSub((int *)&pl_ctl[2], 1);  // after this wave's hand-over (if any) was published
+                    left = true;
+                }
+                if (exhausted && adopter) {
+                    // stay until every retirable wave has signed off and the pool is drained
+                    finished = (pl_ctl[2] <= 0 && pl_ctl[0] >= pl_ctl[1]) || ++spins > (1 << 24);
+                    if (!finished)
+                        __builtin_amdgcn_s_sleep(4);
+                }
+                if (finished) {
                     if (stamps && j0 == 0 && lane == 0) {
                         stamps[5 + 6 * wib] = clock64();  // this wave's last source finished
                         stamps[6 + 6 * wib] = dg_iters;   // evaluation trips of the wave
@@ -429,7 +527,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     }
                     break;
                 }
-                continue;  // all 64 lanes idle: the next trip refills
+                continue;  // idle: the next trip refills / adopts
             }
             T f, fp;
             const bool was_busy = (s.st != ST_DONE);
@@ -625,7 +723,8 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
     const size_t table = ((size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * elem_bytes + 7) / 8 * 8;
-    const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 8;
+    const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
+                         (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int);
     size_t share = (size_t)160 * 1024 / wg_per_cu;
     int64_t max_slots = share > fixed + 64 * slot_bytes ? (int64_t)((share - fixed) / slot_bytes / 64 * 64) : 64;
     if (max_slots > 8128)
