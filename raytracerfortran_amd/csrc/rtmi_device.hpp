@@ -216,9 +216,27 @@ __device__ __forceinline__ void term_guarded(double w, double a, double hv, doub
     tp = __builtin_fma(__builtin_fma(-s3, q3, hv), r3, q3);
 }
 
+// One layer term: tf = (hv*x)/s, tp = hv/((s*s)*s), s = sqrt(1 - xx*vv).  Returns the guard of the fast form.
+template <bool FAST, typename T>
+__device__ __forceinline__ bool layer_term(T xx, T x, T hv, T vv, T &tf, T &tp)
+{
+    const T w = T(1.0) - xx * vv;
+    if constexpr (FAST && std::is_same<T, double>::value) {
+        term_guarded(w, hv * x, hv, tf, tp);
+        return w > 1e-60;
+    } else {
+        const T s = sqrt(w);
+        tf = (hv * x) / s;
+        tp = hv / ((s * s) * s);
+        return true;
+    }
+}
+
 // costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
 // `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
+// Terms are evaluated two at a time (two independent sqrt/divide chains in flight: the evaluation is a long
+// dependent chain, and in the drain a wave has its SIMD to itself) and ADDED strictly in layer order.
 template <bool FAST, typename T>
 __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
                                            T vvl, T R, T &f, T &fp)
@@ -226,38 +244,38 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
     const T xx = x * x;
     T sf = T(0.0), sp = T(0.0);
     bool ok = true;
-    for (int i = 0; i < nfull_wave; ++i) {
-        // lanes whose stack is shorter sit this trip out under EXEC (no selects on the accumulators)
+    int i = 0;
+    for (; i + 1 < nfull_wave; i += 2) {
+        T tf0, tp0, tf1, tp1;
+        const bool g0 = layer_term<FAST>(xx, x, t.HV[i], t.VV[i], tf0, tp0);
+        const bool g1 = layer_term<FAST>(xx, x, t.HV[i + 1], t.VV[i + 1], tf1, tp1);
         if (i < nfull) {
-            const T hv = t.HV[i];
-            const T vv = t.VV[i];
-            const T w = T(1.0) - xx * vv;
-            T tf, tp;
-            if constexpr (FAST && std::is_same<T, double>::value) {
-                ok = ok && (w > 1e-60);
-                term_guarded(w, hv * x, hv, tf, tp);
-            } else {
-                const T s = sqrt(w);
-                tf = (hv * x) / s;
-                tp = hv / ((s * s) * s);
-            }
-            sf = sf + tf;
-            sp = sp + tp;
+            sf = sf + tf0;
+            sp = sp + tp0;
+            ok = ok && g0;
+        }
+        if (i + 1 < nfull) {
+            sf = sf + tf1;
+            sp = sp + tp1;
+            ok = ok && g1;
         }
     }
     {
-        const T w = T(1.0) - xx * vvl;
-        if constexpr (FAST && std::is_same<T, double>::value) {
-            ok = ok && (w > 1e-60);
-            double tf, tp;
-            term_guarded(w, hvl * x, hvl, tf, tp);
-            sf = sf + tf;
-            sp = sp + tp;
-        } else {
-            const T s = sqrt(w);
-            sf = sf + (hvl * x) / s;
-            sp = sp + hvl / ((s * s) * s);
+        // the odd full layer (if any) together with the source's own partial layer
+        T tf0 = T(0.0), tp0 = T(0.0), tfl, tpl;
+        bool g0 = true;
+        const bool odd = i < nfull_wave;  // wave-uniform
+        if (odd)
+            g0 = layer_term<FAST>(xx, x, t.HV[i], t.VV[i], tf0, tp0);
+        const bool gl = layer_term<FAST>(xx, x, hvl, vvl, tfl, tpl);
+        if (odd && i < nfull) {
+            sf = sf + tf0;
+            sp = sp + tp0;
+            ok = ok && g0;
         }
+        sf = sf + tfl;
+        sp = sp + tpl;
+        ok = ok && gl;
     }
     f = R - sf;
     fp = -sp;
