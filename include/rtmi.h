@@ -145,6 +145,8 @@ int rtmi_device_cus(void);
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
  *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
  *                     fewer than g x tail_group remain queued, 0..4096 (default 512, 0 = off)
+ *   "seg_mode"        1: the solve order is cut into one cost-balanced contiguous segment per wave (shorter layer
+ *                     loops, measured neutral overall), 0: one shared queue head (default)
  *   "retire_max"      drain: waves 4.. of a workgroup hand their last <= retire_max live lane states over to
  *                     waves 0..3 and leave, 0..21 (default 8, 0 = off)
  * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN, RTMI_TAIL_GROUP,

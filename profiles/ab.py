@@ -12,7 +12,7 @@ v, d, off, dep = bench.c2_workload(1_000_000)
 dev = "cuda"
 dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
 out = torch.empty(off.size, dtype=torch.float64, device=dev)
-settings = [dict(path=2, waves_per_simd=w, refill_min=m, tail_group=t, retire_max=r) for w in (2, 3, 4) for m in (8, 16) for (t, r) in ((0, 0), (512, 0), (512, 8), (768, 8))]
+settings = [dict(path=2, waves_per_simd=w, refill_min=m, tail_group=512, retire_max=r, seg_mode=g) for w in (3, 4) for g in (0, 1) for m in (4, 8, 16) for r in (8, 16)]
 ROUNDS, STEPS = 7, 10
 res = {i: [] for i in range(len(settings))}
 for r in range(ROUNDS):

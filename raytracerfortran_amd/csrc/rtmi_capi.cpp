@@ -75,13 +75,14 @@ struct Tuning {
     int refill_min;      // idle lanes that trigger a refill
     int tail_group;      // end-game concentration (records per wave group), 0 = off
     int retire_max;      // drain: live lanes a retiring wave hands over (0 = off)
+    int seg_mode;        // 1: per-wave cost-balanced segments, 0: shared queue head
     unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
 };
 
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, 512, 8, nullptr};
+        Tuning v{0, 4, 16, 512, 8, 0, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -345,6 +346,10 @@ int rtmi_set_option(const char *name, int value)
         if (value < 1 || value > 64)
             return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
         t.refill_min = value;
+    } else if (!strcmp(name, "seg_mode")) {
+        if (value < 0 || value > 1)
+            return fail(RTMI_ERR_BAD_ARG, "seg_mode must be 0 or 1");
+        t.seg_mode = value;
     } else if (!strcmp(name, "retire_max")) {
         if (value < 0 || value > 21)
             return fail(RTMI_ERR_BAD_ARG, "retire_max must be in [0, 21]");
@@ -397,6 +402,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.seg_mode = tn.seg_mode;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -517,6 +523,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.seg_mode = tn.seg_mode;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
         fa.nsrc = c.set_n;
@@ -570,6 +577,7 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.seg_mode = tn.seg_mode;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -653,6 +661,7 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.seg_mode = tn.seg_mode;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;

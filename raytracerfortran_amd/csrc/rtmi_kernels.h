@@ -44,6 +44,7 @@ struct FusedArgsT {
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
+    int seg_mode;                // 1: per-wave cost-balanced segments of the solve order, 0: one shared queue head
     int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off, <= 21)
     const T *d_src_offset;  // [nsrc]
     const T *d_src_depth;   // [nsrc]

@@ -170,6 +170,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..28
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
+#define RTMI_RK_DONE 0x40000000u      // rk: finished by its first evaluation (or p0 is NaN): not in the solve order
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
@@ -212,6 +213,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     int *pl_state = pl_slot + RTMI_POOL;                        // st | k << 8 | conv << 16
     volatile int *pl_ready = pl_state + RTMI_POOL;
     volatile int *pl_ctl = pl_ready + RTMI_POOL;                // [0] head, [1] tail, [2] retirable waves still solving
+    // exact solve order + per-wave segments: per 64-slot chunk counts, starts and costs of the two classes
+    uint32_t *ch_cnt = reinterpret_cast<uint32_t *>(const_cast<int *>(pl_ctl) + 4);  // [128] long | short << 16
+    uint32_t *ch_start = ch_cnt + 128;                          // [128] first order[] position: long | short << 16
+    uint32_t *ch_cum = ch_start + 128;                          // [256] exclusive cost prefix: long chunks, short chunks
+    uint32_t *seg_head = ch_cum + 256;                          // [16] next unclaimed order[] position of segment w
+    uint32_t *seg_end = seg_head + 16;                          // [16]
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -358,23 +365,129 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
                     rp[q] = s.x;
+                    k2 |= RTMI_RK_DONE;
                     if (s.conv)
                         k2 |= RTMI_RK_CONV;
                 } else {
                     rp[q] = s.xe;  // BIS0: 1e-10; NEWTON: the first Newton iterate (x == xe)
-                    const bool is_long = (s.st == ST_BIS0);
-                    if (!is_long)
+                    if (s.st != ST_BIS0)
                         k2 |= RTMI_RK_SHORT;
-                    // long class fills order[] from the front, short class from the back
-                    const uint32_t pos = is_long ? atomicAdd(&qctl[2], 1u) : (uint32_t)(nq - 1) - atomicAdd(&qctl[3], 1u);
-                    order[pos] = (uint16_t)q;
                 }
                 rk[q] = k2;
             }
         }
         __syncthreads();
+
+        // ---- a3. exact solve order and per-wave segments -------------------------------------------
+        // order[] = the long class, then the short class, each in slot order (= descending layer index), built
+        // from per-chunk ballots (deterministic).  The order is then cut into one contiguous segment per wave of
+        // equal estimated cost ((layers + 2) x expected evaluations of the class): a wave works inside one or two
+        // layer counts, so its layer loop runs (almost) no idle trips; a wave that empties its segment moves to
+        // the fullest one.
+        const int nchq = (nq + 63) >> 6;  // <= 127
+        for (int c = wib; c < nchq; c += nwib) {
+            const int q = c * 64 + lane;
+            const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
+            const bool todo = !(key & RTMI_RK_DONE);
+            const bool sht = todo && (key & RTMI_RK_SHORT);
+            const bool lng = todo && !sht;
+            const int nlq = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+            int cl = lng ? (nlq + 2) * 13 : 0, cs = sht ? (nlq + 2) * 4 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                cl += __shfl_xor(cl, off, 64);
+                cs += __shfl_xor(cs, off, 64);
+            }
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(lng)) | ((uint32_t)__popcll(__ballot(sht)) << 16);
+            if (lane == 0) {
+                ch_cnt[c] = cnt;
+                ch_cum[c] = (uint32_t)cl;
+                ch_cum[128 + c] = (uint32_t)cs;
+            }
+        }
+        __syncthreads();
+        if (wib == 0) {
+            // lane l owns chunks 2l and 2l+1: exclusive prefixes of counts and costs over chunks
+            const int c0 = 2 * lane, c1 = 2 * lane + 1;
+            const uint32_t n0 = c0 < nchq ? ch_cnt[c0] : 0u, n1 = c1 < nchq ? ch_cnt[c1] : 0u;
+            const uint32_t l0 = c0 < nchq ? ch_cum[c0] : 0u, l1 = c1 < nchq ? ch_cum[c1] : 0u;
+            const uint32_t s0 = c0 < nchq ? ch_cum[128 + c0] : 0u, s1 = c1 < nchq ? ch_cum[128 + c1] : 0u;
+            uint32_t in_n = n0 + n1, in_l = l0 + l1, in_s = s0 + s1;  // counts: two 16-bit fields, no carry (<= 8128)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t on = __shfl_up(in_n, off, 64), ol = __shfl_up(in_l, off, 64), os = __shfl_up(in_s, off, 64);
+                if (lane >= off) {
+                    in_n += on;
+                    in_l += ol;
+                    in_s += os;
+                }
+            }
+            const uint32_t tot_n = __shfl(in_n, 63, 64), tot_l = __shfl(in_l, 63, 64), tot_s = __shfl(in_s, 63, 64);
+            const uint32_t ex_n = in_n - (n0 + n1), ex_l = in_l - (l0 + l1), ex_s = in_s - (s0 + s1);
+            if (c0 < nchq) {
+                ch_start[c0] = ex_n;
+                ch_cum[c0] = ex_l;
+                ch_cum[128 + c0] = ex_s;
+            }
+            if (c1 < nchq) {
+                ch_start[c1] = ex_n + n0;
+                ch_cum[c1] = ex_l + l0;
+                ch_cum[128 + c1] = ex_s + s0;
+            }
+            if (lane == 0) {
+                qctl[2] = tot_n & 0xFFFFu;  // n_long
+                qctl[3] = tot_n >> 16;      // n_short
+            }
+            // segment w starts at the first item (long chunks, then short chunks) whose cost prefix reaches w/nseg
+            // of the total; item -> order[] position
+            const int nseg = nwib;
+            const unsigned long long total = (unsigned long long)tot_l + tot_s;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t start = 0;
+            if (lane > 0 && lane < nseg) {
+                const unsigned long long target = total * (unsigned long long)lane / (unsigned long long)nseg;
+                int lo = 0, hi = 2 * nchq;  // first item with prefix >= target
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const unsigned long long pre = mid < nchq ? (unsigned long long)ch_cum[mid]
+                                                               : (unsigned long long)tot_l + ch_cum[128 + mid - nchq];
+                    if (pre >= target)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                if (lo >= 2 * nchq)
+                    start = (tot_n & 0xFFFFu) + (tot_n >> 16);
+                else if (lo < nchq)
+                    start = ch_start[lo] & 0xFFFFu;
+                else
+                    start = (tot_n & 0xFFFFu) + (ch_start[lo - nchq] >> 16);
+            }
+            const uint32_t nxt = __shfl_down(start, 1, 64);
+            if (lane < nseg) {
+                seg_head[lane] = start;
+                seg_end[lane] = (lane == nseg - 1) ? (tot_n & 0xFFFFu) + (tot_n >> 16) : nxt;
+            }
+        }
+        __syncthreads();
         const int n_long = (int)qctl[2];
         const int n_todo = n_long + (int)qctl[3];  // records that need the solve loop
+        for (int c = wib; c < nchq; c += nwib) {
+            const int q = c * 64 + lane;
+            const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
+            const bool todo = !(key & RTMI_RK_DONE);
+            const bool sht = todo && (key & RTMI_RK_SHORT);
+            const bool lng = todo && !sht;
+            const unsigned long long bl = __ballot(lng), bs = __ballot(sht);
+            const uint32_t st = ch_start[c];
+            if (lng)
+                order[(st & 0xFFFFu) + __popcll(bl & lt_mask)] = (uint16_t)q;
+            if (sht)
+                order[n_long + (st >> 16) + __popcll(bs & lt_mask)] = (uint16_t)q;
+        }
+        __syncthreads();
         if (stamps && j0 == 0 && threadIdx.x == 0)
             stamps[1] = clock64();
 
@@ -397,6 +510,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         const bool adopter = a.retire_max > 0 && nwib > 4 && wib < 4;
         bool left = false;  // (retirable) this wave has signed off from pl_ctl[2]
         int spins = 0;
+        int cur_seg = wib;  // (seg_mode) the segment this wave currently takes from
         int nfull_wave = 0;
         // diagnostic occupancy counters (only touched when stamps are requested)
         unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0;
@@ -406,26 +520,52 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             // End-game concentration: the last records of the queue go to the first waves only (wave group g =
             // wib / 4 stops refilling once fewer than g * tail_group records remain), so that the drain is
             // carried by few, well filled waves instead of every wave at low occupancy.
-            if (!exhausted && tail_group > 0 && wib >= 4 && n_todo - (int)qctl[0] < (wib >> 2) * tail_group) {
+            if (!exhausted && !a.seg_mode && tail_group > 0 && wib >= 4 &&
+                n_todo - (int)qctl[0] < (wib >> 2) * tail_group) {
                 exhausted = true;
                 if (stamps && j0 == 0 && lane == 0)
                     stamps[4 + 6 * wib] = clock64();
             }
             if (!exhausted && nidle >= a.refill_min) {
                 uint32_t base = 0;
-                if (lane == 0)
-                    base = atomicAdd(&qctl[0], (uint32_t)nidle);
-                base = __shfl(base, 0, 64);
-                exhausted = (int)base + nidle >= n_todo;
+                int lim = n_todo;
+                if (a.seg_mode) {
+                    // take from this wave's current segment; when it is empty move to the fullest one
+                    if (lane == 0)
+                        base = atomicAdd(&seg_head[cur_seg], (uint32_t)nidle);
+                    base = __shfl(base, 0, 64);
+                    lim = (int)seg_end[cur_seg];
+                    if ((int)base >= lim) {
+                        int rem = 0;
+                        if (lane < nwib) {
+                            rem = (int)seg_end[lane] - (int)seg_head[lane];
+                            rem = rem > 0 ? rem : 0;
+                        }
+                        int best = (rem << 8) | lane;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const int o = __shfl_xor(best, off, 64);
+                            best = o > best ? o : best;
+                        }
+                        if ((best >> 8) == 0)
+                            exhausted = true;
+                        else
+                            cur_seg = best & 0xFF;
+                    }
+                } else {
+                    if (lane == 0)
+                        base = atomicAdd(&qctl[0], (uint32_t)nidle);
+                    base = __shfl(base, 0, 64);
+                    exhausted = (int)base + nidle >= n_todo;
+                }
                 ++dg_refills;
                 if (stamps && j0 == 0 && exhausted && lane == 0)
                     stamps[4 + 6 * wib] = clock64();  // this wave saw the queue run dry
                 if (s.st == ST_DONE) {
                     const int qi = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
-                    if (qi < n_todo) {
-                        // long class front to back, then the short class from the top of order[] downwards:
-                        // both in descending layer order
-                        slot = (int)order[qi < n_long ? qi : (nq - 1) - (qi - n_long)];
+                    if (qi < lim) {
+                        // long class, then short class, both in descending layer order
+                        slot = (int)order[qi];
                         const uint32_t key = rk[slot];
                         const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
                         lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
@@ -724,7 +864,8 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
         waves = (int)chunks_per_block;  // small inputs: no idle waves
     const size_t table = ((size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * elem_bytes + 7) / 8 * 8;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
-                         (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int);
+                         (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
+                         (128 + 128 + 256 + 32) * sizeof(uint32_t);
     size_t share = (size_t)160 * 1024 / wg_per_cu;
     int64_t max_slots = share > fixed + 64 * slot_bytes ? (int64_t)((share - fixed) / slot_bytes / 64 * 64) : 64;
     if (max_slots > 8128)
