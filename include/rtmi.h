@@ -166,9 +166,10 @@ int rtmi_set_option(const char *name, int value);
  * sources of one model.  d_p_final may be NULL; when given it receives the final
  * ray parameter of each source (NaN for straight top-layer rays), from which the
  * rays.dat records are rebuilt on the host.
- * Source sets of RTMI_FUSED_MIN_NSRC or more take the fused large-N kernel (each wave sorts its
+ * Source sets of RTMI_FUSED_MIN_NSRC or more take the fused large-N kernel (each workgroup sorts its
  * sources by layer in LDS and refills lanes as they finish), smaller ones the plain one-lane-per-
- * source kernel.  Results are bit-identical either way.
+ * source kernel; the batch entry point switches at a quarter of that per model.  Results are
+ * bit-identical either way.
  */
 #define RTMI_FUSED_MIN_NSRC 8192
 int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,

@@ -29,11 +29,16 @@
 //        a2. first evaluation of every record at full occupancy: GetPTime's branch (:136-153), which
 //            also splits the records into a long class (bisection first) and a short class (Newton
 //            from p0); sources converged at p0 are done;
-//        b.  solve: every wave pulls records from the workgroup's queue (long class first); a lane that
-//            finishes takes the next record once `refill_min` lanes are idle, so the evaluation loop
-//            runs with most lanes live instead of waiting for the slowest source; near the end of the
-//            queue the last records go to the first wave groups only (`tail_group`); no global
-//            memory traffic inside the loop (records and results live in LDS);
+//        a3. the solve order (long class, then short class, each by descending layer index) is built
+//            from per-chunk ballots, deterministically; optionally (seg_mode) it is cut into one
+//            cost-balanced contiguous segment per wave;
+//        b.  solve: every wave pulls records from the workgroup's queue; a lane that finishes takes the
+//            next record once `refill_min` lanes are idle, so the evaluation loop runs with most lanes
+//            live instead of waiting for the slowest source; no global memory traffic inside the loop
+//            (records and results live in LDS).  The drain at the end of the queue is shortened by two
+//            measures: the last records go to the first wave groups only (`tail_group`), and waves 4..
+//            hand their last few live lane states over to waves 0..3 through an LDS pool and leave
+//            (`retire_max`), so the stragglers finish with a SIMD to themselves;
 //        c.  time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written to
 //            timeP (the only HBM write); with observations the squared residuals are reduced per
 //            workgroup in a fixed order (deterministic logL).
