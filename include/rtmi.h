@@ -144,13 +144,14 @@ int rtmi_device_cus(void);
  *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
  *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
- *                     fewer than g x tail_group remain queued, 0..4096 (default 512, 0 = off)
- *   "seg_mode"        1: the solve order is cut into one cost-balanced contiguous segment per wave (shorter layer
- *                     loops, measured neutral overall), 0: one shared queue head (default)
- *   "retire_max"      drain: waves 4.. of a workgroup hand their last <= retire_max live lane states over to
- *                     waves 0..3 and leave, 0..21 (default 8, 0 = off)
+ *                     fewer than g x tail_group remain queued, 0..4096 (default 256, 0 = off)
+ *   "promote_age"     waves 4.. of a workgroup hand a source over to the express waves 0..3 (one per SIMD) once it
+ *                     has taken this many evaluation trips, 0..64 (default 10, 0 = off; applies to rounds of at
+ *                     least two records per lane)
+ *   "retire_max"      drain: waves 4.. hand their last <= retire_max live lanes over and leave, 0..64
+ *                     (default 8, 0 = off)
  * Environment defaults: RTMI_FORCE_PATH=plain|fused, RTMI_SOLVE_WAVES, RTMI_REFILL_MIN, RTMI_TAIL_GROUP,
- * RTMI_RETIRE_MAX.
+ * RTMI_RETIRE_MAX, RTMI_PROMOTE_AGE.
  */
 int rtmi_set_option(const char *name, int value);
 
@@ -220,12 +221,16 @@ int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double 
                            unsigned long long *d_mismatch, void *stream);
 
 /*
- * Diagnostic: while d_stamps != NULL, every fused-kernel launch of rtmi_trace_device writes, per
- * workgroup, the shader-clock ticks at {start, sorted, solved, times written} of its first round to
- * d_stamps[100*workgroup + 0..3], and per wave w six words at d_stamps[100*workgroup + 4 + 6w ...]:
- * {clock: queue seen empty, clock: last source finished, evaluation trips, sum of live lanes over trips,
- * sum of layer-loop lengths over trips, useful layer terms | refill events << 40}
- * (device buffer of 100 x 8 B x 2 x CUs).  NULL switches off.
+ * Diagnostic: while d_stamps != NULL, every fused-kernel launch of rtmi_trace_device runs the instrumented build of
+ * the kernel, which writes 200 words per workgroup (first round only), in shader-clock ticks:
+ *   d_stamps[200*wg + 0..3]   clock at {start, solve order built, solved, times written}
+ *   d_stamps[200*wg + 4..6]   clock at {bins counted, records in their slots, first evaluation done}
+ *   d_stamps[200*wg + 8 + 12*w + 0..11], per wave w: {clock: queue seen empty, clock: last source finished,
+ *       evaluation trips, sum of live lanes over trips, sum of layer-loop lengths over trips,
+ *       useful layer terms | refill events << 40, and the ticks the wave spent in the six sections of a trip:
+ *       tail check, hand-over, adoption, refill, wave maximum + exit test, evaluation}
+ * (device buffer of 200 x 8 B x 2 x CUs).  NULL switches back to the production kernel, which carries no
+ * instrumentation.
  */
 int rtmi_debug_stamps(unsigned long long *d_stamps);
 

@@ -8,11 +8,12 @@ import torch
 import raytracerfortran_amd as rt
 import bench
 rt.load_library(); rt.init(0)
-v, d, off, dep = bench.c2_workload(1_000_000)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+v, d, off, dep = bench.c2_workload(N)
 dev = "cuda"
 dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
 out = torch.empty(off.size, dtype=torch.float64, device=dev)
-settings = [dict(path=2, waves_per_simd=w, refill_min=m, tail_group=512, retire_max=r, seg_mode=g) for w in (3, 4) for g in (0, 1) for m in (4, 8, 16) for r in (8, 16)]
+settings = [dict(path=2, waves_per_simd=4, refill_min=m, tail_group=t, retire_max=r, promote_age=p) for m in (8, 16) for t in (0, 64, 128, 256, 512) for r in (8, 16) for p in (8, 10, 12)]
 ROUNDS, STEPS = 7, 10
 res = {i: [] for i in range(len(settings))}
 for r in range(ROUNDS):

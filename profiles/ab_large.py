@@ -13,7 +13,7 @@ off = rng.uniform(10, 8000, n); dep = rng.uniform(50, d[-1] + 500, n)
 dev = "cuda"
 a = [torch.tensor(x, device=dev) for x in (v, d, off, dep)]
 out = torch.empty(n, dtype=torch.float64, device=dev)
-settings = [dict(waves_per_simd=4, refill_min=16, tail_group=t, retire_max=r, seg_mode=g) for g in (0, 1) for t in (0, 512) for r in (0, 8, 16)]
+settings = [dict(waves_per_simd=4, refill_min=16, tail_group=t, retire_max=r, promote_age=p) for p in (0, 8) for t in (0, 512) for r in (0, 8, 16)]
 res = {i: [] for i in range(len(settings))}
 for r in range(4):
     for i, st in enumerate(settings):

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""profiles/ab_x.py N [N ...] -- tail_group x promote_age x retire_max at several source counts (interleaved A/B)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracerfortran_amd as rt
+import bench
+rt.load_library(); rt.init(0)
+dev = "cuda"
+for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
+    v, d, off, dep = bench.c2_workload(N)
+    dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
+    out = torch.empty(off.size, dtype=torch.float64, device=dev)
+    settings = [("t%d p%d r%d" % (t, p, r), dict(tail_group=t, promote_age=p, retire_max=r)) for t in (0, 256, 512) for p in (0, 10) for r in (0, 8)]
+    res = {n: [] for n, _ in settings}
+    for r in range(7):
+        for n, val in settings:
+            for k, x in val.items():
+                rt.set_option(k, x)
+            rt.trace_device(dv, dd, do, dz, timeP=out); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                rt.trace_device(dv, dd, do, dz, timeP=out)
+            e1.record(); torch.cuda.synchronize()
+            res[n].append(e0.elapsed_time(e1) / 10)
+    print("N =", N)
+    for n, _ in settings:
+        a = np.array(res[n]); print("  %-12s median %.4f ms  min %.4f ms" % (n, np.median(a), a.min()))

@@ -75,14 +75,14 @@ struct Tuning {
     int refill_min;      // idle lanes that trigger a refill
     int tail_group;      // end-game concentration (records per wave group), 0 = off
     int retire_max;      // drain: live lanes a retiring wave hands over (0 = off)
-    int seg_mode;        // 1: per-wave cost-balanced segments, 0: shared queue head
+    int promote_age;     // trips after which a local wave hands a source to the express waves (0 = off)
     unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
 };
 
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, 512, 8, 0, nullptr};
+        Tuning v{0, 4, 16, 256, 8, 10, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -96,7 +96,9 @@ Tuning &tuning()
         if (const char *e = getenv("RTMI_TAIL_GROUP"))
             v.tail_group = atoi(e) >= 0 ? atoi(e) : v.tail_group;
         if (const char *e = getenv("RTMI_RETIRE_MAX"))
-            v.retire_max = (atoi(e) >= 0 && atoi(e) <= 21) ? atoi(e) : v.retire_max;
+            v.retire_max = (atoi(e) >= 0 && atoi(e) <= 64) ? atoi(e) : v.retire_max;
+        if (const char *e = getenv("RTMI_PROMOTE_AGE"))
+            v.promote_age = (atoi(e) >= 0 && atoi(e) <= 64) ? atoi(e) : v.promote_age;
         return v;
     }();
     return t;
@@ -346,13 +348,13 @@ int rtmi_set_option(const char *name, int value)
         if (value < 1 || value > 64)
             return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
         t.refill_min = value;
-    } else if (!strcmp(name, "seg_mode")) {
-        if (value < 0 || value > 1)
-            return fail(RTMI_ERR_BAD_ARG, "seg_mode must be 0 or 1");
-        t.seg_mode = value;
+    } else if (!strcmp(name, "promote_age")) {
+        if (value < 0 || value > 64)
+            return fail(RTMI_ERR_BAD_ARG, "promote_age must be in [0, 64]");
+        t.promote_age = value;
     } else if (!strcmp(name, "retire_max")) {
-        if (value < 0 || value > 21)
-            return fail(RTMI_ERR_BAD_ARG, "retire_max must be in [0, 21]");
+        if (value < 0 || value > 64)
+            return fail(RTMI_ERR_BAD_ARG, "retire_max must be in [0, 64]");
         t.retire_max = value;
     } else if (!strcmp(name, "tail_group")) {
         if (value < 0 || value > 4096)
@@ -402,7 +404,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.seg_mode = tn.seg_mode;
+        fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -523,7 +525,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.seg_mode = tn.seg_mode;
+        fa.promote_age = tn.promote_age;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
         fa.nsrc = c.set_n;
@@ -577,7 +579,7 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.seg_mode = tn.seg_mode;
+        fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -661,7 +663,7 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.seg_mode = tn.seg_mode;
+        fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;

@@ -7,8 +7,10 @@
 
 #define RTMI_BLOCK 256          // threads per workgroup (4 waves: one per SIMD of a CU)
 #define RTMI_BLOCKS_PER_CU 16   // grid cap = CUs x this; further tiles are grid-strided
-#define RTMI_STAMPS_PER_WG 100  // diagnostic words per workgroup: 4 phase clocks + 6 per wave
-#define RTMI_POOL 256  // suspended lane states a workgroup can hand over in the drain (>= 12 waves x 16 + slack)
+#define RTMI_STAMPS_PER_WAVE 12
+#define RTMI_STAMPS_PER_WG (8 + 16 * RTMI_STAMPS_PER_WAVE)  // diagnostic words per workgroup: 8 phase clocks + 12 per wave
+#define RTMI_POOL 256         // slots of the hand-over ring (power of two)
+#define RTMI_PROMOTE_MIN 4    // old sources a wave collects before one hand-over
 #define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
 
 namespace rtmi {
@@ -44,8 +46,8 @@ struct FusedArgsT {
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
-    int seg_mode;                // 1: per-wave cost-balanced segments of the solve order, 0: one shared queue head
-    int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off, <= 21)
+    int promote_age;             // local waves hand a source to the express waves after this many trips (0 = off)
+    int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off)
     const T *d_src_offset;  // [nsrc]
     const T *d_src_depth;   // [nsrc]
     int64_t nsrc;

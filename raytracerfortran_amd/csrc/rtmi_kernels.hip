@@ -30,15 +30,17 @@
 //            also splits the records into a long class (bisection first) and a short class (Newton
 //            from p0); sources converged at p0 are done;
 //        a3. the solve order (long class, then short class, each by descending layer index) is built
-//            from per-chunk ballots, deterministically; optionally (seg_mode) it is cut into one
-//            cost-balanced contiguous segment per wave;
+//            from per-chunk ballots, deterministically;
 //        b.  solve: every wave pulls records from the workgroup's queue; a lane that finishes takes the
 //            next record once `refill_min` lanes are idle, so the evaluation loop runs with most lanes
 //            live instead of waiting for the slowest source; no global memory traffic inside the loop
-//            (records and results live in LDS).  The drain at the end of the queue is shortened by two
-//            measures: the last records go to the first wave groups only (`tail_group`), and waves 4..
-//            hand their last few live lane states over to waves 0..3 through an LDS pool and leave
-//            (`retire_max`), so the stragglers finish with a SIMD to themselves;
+//            (records and results live in LDS).  The phase is bound by its critical path (a source may
+//            need 38 evaluations in sequence, and a trip of a wave that shares its SIMD with three
+//            others takes 2-3x the wall time of a wave running alone), so waves 0..3 -- one per SIMD --
+//            are "express" waves and the other waves hand them, through an LDS
+//            ring, every source that has already taken `promote_age` trips and, in the drain, their last
+//            `retire_max` live lanes (resumable lane states); `tail_group` steers the last records of the
+//            queue to the first wave groups;
 //        c.  time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written to
 //            timeP (the only HBM write); with observations the squared residuals are reduced per
 //            workgroup in a fixed order (deterministic logL).
@@ -181,7 +183,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
 // grid.y = model (many models over one shared source set: loglhood.f90:128-146 per proposal); every
 // workgroup row b of a model owns chunks b, b + gridDim.x, ... of the sources.
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
     extern __shared__ double lds_raw[];  // 8-byte aligned storage for either element type
@@ -216,14 +218,13 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     T *pl_dx = pl_xb + RTMI_POOL;
     int *pl_slot = reinterpret_cast<int *>(pl_dx + RTMI_POOL);
     int *pl_state = pl_slot + RTMI_POOL;                        // st | k << 8 | conv << 16
-    volatile int *pl_ready = pl_state + RTMI_POOL;
-    volatile int *pl_ctl = pl_ready + RTMI_POOL;                // [0] head, [1] tail, [2] retirable waves still solving
-    // exact solve order + per-wave segments: per 64-slot chunk counts, starts and costs of the two classes
-    uint32_t *ch_cnt = reinterpret_cast<uint32_t *>(const_cast<int *>(pl_ctl) + 4);  // [128] long | short << 16
-    uint32_t *ch_start = ch_cnt + 128;                          // [128] first order[] position: long | short << 16
-    uint32_t *ch_cum = ch_start + 128;                          // [256] exclusive cost prefix: long chunks, short chunks
-    uint32_t *seg_head = ch_cum + 256;                          // [16] next unclaimed order[] position of segment w
-    uint32_t *seg_end = seg_head + 16;                          // [16]
+    // the ring's flags and control words are polled: volatile, and typed as LDS so that the polls are ds_read, not flat loads
+    typedef __attribute__((address_space(3))) int lds_int;
+    volatile lds_int *pl_ready = (volatile lds_int *)(pl_state + RTMI_POOL);
+    volatile lds_int *pl_ctl = pl_ready + RTMI_POOL;            // [0] tail (reserved), [1] head (claimed), [2] local waves still solving
+    // exact solve order: per 64-slot chunk, counts and first order[] positions of the two classes
+    uint32_t *ch_cnt = reinterpret_cast<uint32_t *>(pl_state + 2 * RTMI_POOL + 4);  // [128] long | short << 16
+    uint32_t *ch_start = ch_cnt + 128;                          // [128] long | short << 16
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
 
     // Diagnostic phase clocks (NULL in normal runs): per workgroup {start, after sort, after solve, after time}
     // of its FIRST round, in shader-clock ticks.  The stamps go to a buffer nothing else reads.
-    unsigned long long *stamps = a.d_stamps ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
+    unsigned long long *stamps = (DIAG && a.d_stamps) ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
     for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
         // ---- a. load + workgroup-local STABLE counting sort ------------------------------------
         // No atomics: lane b of each wave counts the wave's records of bin b in a register (one
         // ballot per distinct bin of a chunk), so slots -- and with them the summation order of the
         // fused logL -- are the same on every run.
-        if (stamps && j0 == 0 && threadIdx.x == 0)
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[0] = clock64();
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t mycnt = 0;
@@ -266,6 +267,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         }
         hist[wib * 64 + lane] = mycnt;
         __syncthreads();
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[4] = clock64();  // depths loaded, bins counted
         if (wib == 0) {
             uint32_t tot = 0;
             for (int w = 0; w < nwib; ++w)
@@ -341,6 +344,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
         }
         __syncthreads();
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[5] = clock64();  // records in their slots, p0 computed
         const int nq = (int)qctl[1];
 
         // ---- a2. first evaluation of every record, in sorted order (one layer count per wave) -------
@@ -382,98 +387,43 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
         }
         __syncthreads();
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[6] = clock64();  // first evaluation done
 
-        // ---- a3. exact solve order and per-wave segments -------------------------------------------
+        // ---- a3. exact solve order ----------------------------------------------------------------------
         // order[] = the long class, then the short class, each in slot order (= descending layer index), built
-        // from per-chunk ballots (deterministic).  The order is then cut into one contiguous segment per wave of
-        // equal estimated cost ((layers + 2) x expected evaluations of the class): a wave works inside one or two
-        // layer counts, so its layer loop runs (almost) no idle trips; a wave that empties its segment moves to
-        // the fullest one.
+        // from per-chunk ballots (deterministic).
         const int nchq = (nq + 63) >> 6;  // <= 127
         for (int c = wib; c < nchq; c += nwib) {
             const int q = c * 64 + lane;
             const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
             const bool todo = !(key & RTMI_RK_DONE);
             const bool sht = todo && (key & RTMI_RK_SHORT);
-            const bool lng = todo && !sht;
-            const int nlq = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
-            int cl = lng ? (nlq + 2) * 13 : 0, cs = sht ? (nlq + 2) * 4 : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                cl += __shfl_xor(cl, off, 64);
-                cs += __shfl_xor(cs, off, 64);
-            }
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(lng)) | ((uint32_t)__popcll(__ballot(sht)) << 16);
-            if (lane == 0) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(todo && !sht)) | ((uint32_t)__popcll(__ballot(sht)) << 16);
+            if (lane == 0)
                 ch_cnt[c] = cnt;
-                ch_cum[c] = (uint32_t)cl;
-                ch_cum[128 + c] = (uint32_t)cs;
-            }
         }
         __syncthreads();
         if (wib == 0) {
-            // lane l owns chunks 2l and 2l+1: exclusive prefixes of counts and costs over chunks
+            // lane l owns chunks 2l and 2l+1: exclusive prefix of the two counts (16-bit fields, no carry: <= 8128)
             const int c0 = 2 * lane, c1 = 2 * lane + 1;
             const uint32_t n0 = c0 < nchq ? ch_cnt[c0] : 0u, n1 = c1 < nchq ? ch_cnt[c1] : 0u;
-            const uint32_t l0 = c0 < nchq ? ch_cum[c0] : 0u, l1 = c1 < nchq ? ch_cum[c1] : 0u;
-            const uint32_t s0 = c0 < nchq ? ch_cum[128 + c0] : 0u, s1 = c1 < nchq ? ch_cum[128 + c1] : 0u;
-            uint32_t in_n = n0 + n1, in_l = l0 + l1, in_s = s0 + s1;  // counts: two 16-bit fields, no carry (<= 8128)
+            uint32_t in_n = n0 + n1;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t on = __shfl_up(in_n, off, 64), ol = __shfl_up(in_l, off, 64), os = __shfl_up(in_s, off, 64);
-                if (lane >= off) {
+                const uint32_t on = __shfl_up(in_n, off, 64);
+                if (lane >= off)
                     in_n += on;
-                    in_l += ol;
-                    in_s += os;
-                }
             }
-            const uint32_t tot_n = __shfl(in_n, 63, 64), tot_l = __shfl(in_l, 63, 64), tot_s = __shfl(in_s, 63, 64);
-            const uint32_t ex_n = in_n - (n0 + n1), ex_l = in_l - (l0 + l1), ex_s = in_s - (s0 + s1);
-            if (c0 < nchq) {
+            const uint32_t tot_n = __shfl(in_n, 63, 64);
+            const uint32_t ex_n = in_n - (n0 + n1);
+            if (c0 < nchq)
                 ch_start[c0] = ex_n;
-                ch_cum[c0] = ex_l;
-                ch_cum[128 + c0] = ex_s;
-            }
-            if (c1 < nchq) {
+            if (c1 < nchq)
                 ch_start[c1] = ex_n + n0;
-                ch_cum[c1] = ex_l + l0;
-                ch_cum[128 + c1] = ex_s + s0;
-            }
             if (lane == 0) {
                 qctl[2] = tot_n & 0xFFFFu;  // n_long
                 qctl[3] = tot_n >> 16;      // n_short
-            }
-            // segment w starts at the first item (long chunks, then short chunks) whose cost prefix reaches w/nseg
-            // of the total; item -> order[] position
-            const int nseg = nwib;
-            const unsigned long long total = (unsigned long long)tot_l + tot_s;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            uint32_t start = 0;
-            if (lane > 0 && lane < nseg) {
-                const unsigned long long target = total * (unsigned long long)lane / (unsigned long long)nseg;
-                int lo = 0, hi = 2 * nchq;  // first item with prefix >= target
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const unsigned long long pre = mid < nchq ? (unsigned long long)ch_cum[mid]
-                                                               : (unsigned long long)tot_l + ch_cum[128 + mid - nchq];
-                    if (pre >= target)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                if (lo >= 2 * nchq)
-                    start = (tot_n & 0xFFFFu) + (tot_n >> 16);
-                else if (lo < nchq)
-                    start = ch_start[lo] & 0xFFFFu;
-                else
-                    start = (tot_n & 0xFFFFu) + (ch_start[lo - nchq] >> 16);
-            }
-            const uint32_t nxt = __shfl_down(start, 1, 64);
-            if (lane < nseg) {
-                seg_head[lane] = start;
-                seg_end[lane] = (lane == nseg - 1) ? (tot_n & 0xFFFFu) + (tot_n >> 16) : nxt;
             }
         }
         __syncthreads();
@@ -493,10 +443,20 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 order[n_long + (st >> 16) + __popcll(bs & lt_mask)] = (uint16_t)q;
         }
         __syncthreads();
-        if (stamps && j0 == 0 && threadIdx.x == 0)
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[1] = clock64();
 
         // ---- b. solve: every wave pulls from the workgroup's queue, lanes refill as they finish ----
+        //
+        // The solve phase is bound by its critical path as much as by throughput: a source may need 38
+        // evaluations one after the other, and with four waves sharing a SIMD one trip of a wave takes ~10-12k
+        // cycles of wall time against ~4.5k when the wave has the SIMD's issue slots to itself.  Hence two kinds
+        // of waves (when the workgroup has more than four):
+        //   express waves 0..3 (one per SIMD) prefer, over fresh records,
+        //     the sources other waves hand to them through an LDS ring;
+        //   local waves 4.. hand over ("promote") every source that has already taken `promote_age` trips -- the
+        //     ones that turn out to be long -- and, in the drain, their last `retire_max` live lanes, then leave.
+        // A handed-over source is resumable state: slot, iterate, bracket, solver state, trip counter.
         Lane<T> s;
         s.st = ST_DONE;
         s.nfull = 0;
@@ -505,70 +465,167 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         s.conv = false;
         s.numer_ok = true;
         int slot = 0;
+        int age = 0;             // trips this lane's source has taken in this wave
         bool exhausted = false;  // wave-uniform: the queue head has passed n_todo
         const int tail_group = a.tail_group < n_todo / 6 ? a.tail_group : n_todo / 6;  // short rounds: keep every wave fed
-        // Wave retirement (the drain): once the queue is empty the live lanes of every wave thin out, and sixteen
-        // waves at a few lanes each cost sixteen waves' worth of issue slots per trip.  Waves 4.. therefore hand
-        // their last `retire_max` live lane states over (LDS pool) and leave; waves 0..3 -- one per SIMD -- adopt
-        // them into their idle lanes and finish them with the SIMD to themselves.
-        const bool retirable = a.retire_max > 0 && nwib > 4 && wib >= 4;
-        const bool adopter = a.retire_max > 0 && nwib > 4 && wib < 4;
-        bool left = false;  // (retirable) this wave has signed off from pl_ctl[2]
+        // hand-overs pay once a round holds at least a record per lane (drain) or two (promotion); below that
+        // every wave is in its end-game from the start
+        const int promote_age = n_todo >= 2 * (int)blockDim.x ? a.promote_age : 0;
+        const bool split = nwib > 4 && n_todo >= (int)blockDim.x && (a.retire_max > 0 || promote_age > 0);
+        const bool local = split && wib >= 4;
+        const bool express = split && wib < 4;
+        bool left = false;  // (local) this wave has signed off from rg[3]
         int spins = 0;
-        int cur_seg = wib;  // (seg_mode) the segment this wave currently takes from
         int nfull_wave = 0;
         // diagnostic occupancy counters (only touched when stamps are requested)
-        unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0;
+        unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0, dg_t0 = 0, dg_t1 = 0;
+        unsigned long long dg_sec[6] = {0, 0, 0, 0, 0, 0};  // ticks in: tail check, hand-over, adoption, refill, wave max + exit test, evaluation
         for (;;) {
-            const unsigned long long idle = __ballot(s.st == ST_DONE);
-            const int nidle = __popcll(idle);
+            if (DIAG && stamps)
+                dg_t0 = clock64();
+            unsigned long long idle = __ballot(s.st == ST_DONE);
+            int nidle = __popcll(idle);
+            bool changed = false;
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[0] += dg_t1 - dg_t0;
+                dg_t0 = dg_t1;
+            }
+
+            // -- local waves: hand over old sources (any time) or the last live lanes (drain) ------------
+            if (local && nidle < 64) {
+                const bool old_src = promote_age > 0 && s.st != ST_DONE && age >= promote_age;
+                const bool drain = exhausted && 64 - nidle <= a.retire_max;
+                const unsigned long long pm = drain ? ~idle : __ballot(old_src);
+                const int np = __popcll(pm);
+                if (np > 0 && (drain || np >= RTMI_PROMOTE_MIN || exhausted)) {
+                    int base = -1;
+                    if (lane == 0) {
+                        int tl = pl_ctl[0];
+                        for (;;) {
+                            if (tl - pl_ctl[1] + np > RTMI_POOL)  // claimed-but-unread slots count as occupied
+                                break;
+                            const int prev = atomicCAS(pl_state + 2 * RTMI_POOL + 0, tl, tl + np);
+                            if (prev == tl) {
+                                base = tl;
+                                break;
+                            }
+                            tl = prev;
+                        }
+                    }
+                    base = __shfl(base, 0, 64);
+                    if (base >= 0) {
+                        if ((pm >> lane) & 1ull) {
+                            const int i = base + __popcll(pm & lt_mask);
+                            const int e = i & (RTMI_POOL - 1), gen = i / RTMI_POOL + 1;
+                            int guard = 0;  // the slot's previous tenant must have been read
+                            while (pl_ready[e] != -(gen - 1) && ++guard < (1 << 22))
+                                __builtin_amdgcn_s_sleep(1);
+                            pl_xe[e] = s.xe;
+                            pl_x[e] = s.x;
+                            pl_xb[e] = s.xb;
+                            pl_dx[e] = s.dx;
+                            pl_slot[e] = slot;
+                            pl_state[e] = s.st | (s.k << 8) | (s.conv ? 1 << 16 : 0);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            pl_ready[e] = gen;
+                            s.st = ST_DONE;
+                        }
+                        idle = __ballot(s.st == ST_DONE);
+                        nidle = __popcll(idle);
+                        changed = true;
+                    }
+                }
+            }
+
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[1] += dg_t1 - dg_t0;
+                dg_t0 = dg_t1;
+            }
+            // -- express waves: adopt handed-over sources into idle lanes ----------------------------------
+            if (express && nidle > 0 && pl_ctl[1] < pl_ctl[0]) {
+                int base = 0, take = 0;
+                if (lane == 0) {
+                    int head = pl_ctl[1];
+                    for (;;) {
+                        const int avail = pl_ctl[0] - head;
+                        take = avail < nidle ? avail : nidle;
+                        if (take <= 0) {
+                            take = 0;
+                            break;
+                        }
+                        const int prev = atomicCAS(pl_state + 2 * RTMI_POOL + 1, head, head + take);
+                        if (prev == head)
+                            break;
+                        head = prev;
+                    }
+                    base = head;
+                }
+                base = __shfl(base, 0, 64);
+                take = __shfl(take, 0, 64);
+                if (take > 0) {
+                    const int r = __popcll(idle & lt_mask);
+                    if (s.st == ST_DONE && r < take) {
+                        const int i = base + r;
+                        const int e = i & (RTMI_POOL - 1), gen = i / RTMI_POOL + 1;
+                        int guard = 0;
+                        while (pl_ready[e] != gen && ++guard < (1 << 22))
+                            __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        slot = pl_slot[e];
+                        const int ps = pl_state[e];
+                        s.xe = pl_xe[e];
+                        s.x = pl_x[e];
+                        s.xb = pl_xb[e];
+                        s.dx = pl_dx[e];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        pl_ready[e] = -gen;  // slot read: free for the next tenant
+                        const uint32_t key = rk[slot];
+                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                        const T keep_xe = s.xe, keep_x = s.x, keep_xb = s.xb, keep_dx = s.dx;
+                        lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
+                        s.xe = keep_xe;
+                        s.x = keep_x;
+                        s.xb = keep_xb;
+                        s.dx = keep_dx;
+                        s.st = ps & 0xFF;
+                        s.k = (ps >> 8) & 0xFF;
+                        s.conv = (ps >> 16) & 1;
+                        age = 0;
+                    }
+                    idle = __ballot(s.st == ST_DONE);
+                    nidle = __popcll(idle);
+                    changed = true;
+                }
+            }
+
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[2] += dg_t1 - dg_t0;
+                dg_t0 = dg_t1;
+            }
+            // -- fresh records from the queue -----------------------------------------------------------------
             // End-game concentration: the last records of the queue go to the first waves only (wave group g =
-            // wib / 4 stops refilling once fewer than g * tail_group records remain), so that the drain is
-            // carried by few, well filled waves instead of every wave at low occupancy.
-            if (!exhausted && !a.seg_mode && tail_group > 0 && wib >= 4 &&
+            // wib / 4 stops refilling once fewer than g * tail_group records remain).
+            if (!exhausted && nidle >= a.refill_min && tail_group > 0 && wib >= 4 &&
                 n_todo - (int)qctl[0] < (wib >> 2) * tail_group) {
                 exhausted = true;
-                if (stamps && j0 == 0 && lane == 0)
-                    stamps[4 + 6 * wib] = clock64();
+                if (DIAG && stamps && j0 == 0 && lane == 0)
+                    stamps[8 + RTMI_STAMPS_PER_WAVE * wib] = clock64();
             }
             if (!exhausted && nidle >= a.refill_min) {
                 uint32_t base = 0;
-                int lim = n_todo;
-                if (a.seg_mode) {
-                    // take from this wave's current segment; when it is empty move to the fullest one
-                    if (lane == 0)
-                        base = atomicAdd(&seg_head[cur_seg], (uint32_t)nidle);
-                    base = __shfl(base, 0, 64);
-                    lim = (int)seg_end[cur_seg];
-                    if ((int)base >= lim) {
-                        int rem = 0;
-                        if (lane < nwib) {
-                            rem = (int)seg_end[lane] - (int)seg_head[lane];
-                            rem = rem > 0 ? rem : 0;
-                        }
-                        int best = (rem << 8) | lane;
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const int o = __shfl_xor(best, off, 64);
-                            best = o > best ? o : best;
-                        }
-                        if ((best >> 8) == 0)
-                            exhausted = true;
-                        else
-                            cur_seg = best & 0xFF;
-                    }
-                } else {
-                    if (lane == 0)
-                        base = atomicAdd(&qctl[0], (uint32_t)nidle);
-                    base = __shfl(base, 0, 64);
-                    exhausted = (int)base + nidle >= n_todo;
-                }
+                if (lane == 0)
+                    base = atomicAdd(&qctl[0], (uint32_t)nidle);
+                base = __shfl(base, 0, 64);
+                exhausted = (int)base + nidle >= n_todo;
                 ++dg_refills;
-                if (stamps && j0 == 0 && exhausted && lane == 0)
-                    stamps[4 + 6 * wib] = clock64();  // this wave saw the queue run dry
+                if (DIAG && stamps && j0 == 0 && exhausted && lane == 0)
+                    stamps[8 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave saw the queue run dry
                 if (s.st == ST_DONE) {
-                    const int qi = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
-                    if (qi < lim) {
+                    const int qi = (int)base + __popcll(idle & lt_mask);
+                    if (qi < n_todo) {
                         // long class, then short class, both in descending layer order
                         slot = (int)order[qi];
                         const uint32_t key = rk[slot];
@@ -581,94 +638,41 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         } else {
                             s.st = ST_BIS0;    // solvebst(1d-10, ...): rp holds x1 = 1e-10
                         }
+                        age = 0;
                     }
                 }
-                nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
-            } else if (exhausted && retirable && !left && nidle < 64 && 64 - nidle <= a.retire_max) {
-                // hand the live lanes over and leave
-                const unsigned long long livem = ~idle;
-                const int nlive = 64 - nidle;
-                int base = 0;
-                if (lane == 0)
-                    base = atomicAdd((int *)&pl_ctl[1], nlive);
-                base = __shfl(base, 0, 64);
-                if (s.st != ST_DONE) {
-                    const int e = base + __popcll(livem & lt_mask);  // < RTMI_POOL: at most 12 waves x retire_max
-                    pl_xe[e] = s.xe;
-                    pl_x[e] = s.x;
-                    pl_xb[e] = s.xb;
-                    pl_dx[e] = s.dx;
-                    pl_slot[e] = slot;
-                    pl_state[e] = s.st | (s.k << 8) | (s.conv ? 1 << 16 : 0);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    pl_ready[e] = 1;
-                    s.st = ST_DONE;
-                }
-            } else if (exhausted && adopter && nidle > 0) {
-                // adopt suspended lane states into the idle lanes
-                int base = 0, take = 0;
-                if (lane == 0) {
-                    int head = pl_ctl[0];
-                    for (;;) {
-                        const int avail = pl_ctl[1] - head;
-                        take = avail < nidle ? avail : nidle;
-                        if (take <= 0) {
-                            take = 0;
-                            break;
-                        }
-                        const int prev = atomicCAS((int *)&pl_ctl[0], head, head + take);
-                        if (prev == head)
-                            break;
-                        head = prev;
-                    }
-                    base = head;
-                }
-                base = __shfl(base, 0, 64);
-                take = __shfl(take, 0, 64);
-                if (take > 0) {
-                    const int r = __popcll(idle & lt_mask);
-                    if (s.st == ST_DONE && r < take) {
-                        const int e = base + r;
-                        int guard = 0;
-                        while (pl_ready[e] == 0 && ++guard < (1 << 22))
-                            __builtin_amdgcn_s_sleep(1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        slot = pl_slot[e];
-                        const uint32_t key = rk[slot];
-                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
-                        lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
-                        const int ps = pl_state[e];
-                        s.xe = pl_xe[e];
-                        s.x = pl_x[e];
-                        s.xb = pl_xb[e];
-                        s.dx = pl_dx[e];
-                        s.st = ps & 0xFF;
-                        s.k = (ps >> 8) & 0xFF;
-                        s.conv = (ps >> 16) & 1;
-                    }
-                    nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
-                }
+                changed = true;
             }
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[3] += dg_t1 - dg_t0;
+                dg_t0 = dg_t1;
+            }
+            if (changed)
+                nfull_wave = wave_max_i32(s.st != ST_DONE ? s.nfull : 0);
+
             if (__all(s.st == ST_DONE)) {
                 bool finished = exhausted;
-                if (exhausted && retirable && !left) {
+                if (exhausted && local && !left) {
                     if (lane == 0)
-                        atomicSub((int *)&pl_ctl[2], 1);  // after this wave's hand-over (if any) was published
+                        atomicSub(pl_state + 2 * RTMI_POOL + 2, 1);  // after this wave's hand-overs were published
                     left = true;
                 }
-                if (exhausted && adopter) {
-                    // stay until every retirable wave has signed off and the pool is drained
-                    finished = (pl_ctl[2] <= 0 && pl_ctl[0] >= pl_ctl[1]) || ++spins > (1 << 24);
+                if (exhausted && express) {
+                    // stay until every local wave has signed off and the ring is drained
+                    finished = (pl_ctl[2] <= 0 && pl_ctl[1] >= pl_ctl[0]) || ++spins > (1 << 24);
                     if (!finished)
                         __builtin_amdgcn_s_sleep(4);
                 }
                 if (finished) {
-                    if (stamps && j0 == 0 && lane == 0) {
-                        stamps[5 + 6 * wib] = clock64();  // this wave's last source finished
-                        stamps[6 + 6 * wib] = dg_iters;   // evaluation trips of the wave
-                        stamps[7 + 6 * wib] = dg_busy;    // sum over trips of lanes carrying a live source
-                        stamps[8 + 6 * wib] = dg_trips;   // sum over trips of layer-loop length (nfull_wave + 1)
-                        stamps[9 + 6 * wib] = dg_terms | (dg_refills << 40);  // useful layer terms | refill events
+                    if (DIAG && stamps && j0 == 0 && lane == 0) {
+                        stamps[9 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave's last source finished
+                        stamps[10 + RTMI_STAMPS_PER_WAVE * wib] = dg_iters;   // evaluation trips of the wave
+                        stamps[11 + RTMI_STAMPS_PER_WAVE * wib] = dg_busy;    // sum over trips of lanes carrying a live source
+                        stamps[12 + RTMI_STAMPS_PER_WAVE * wib] = dg_trips;  // sum over trips of layer-loop length (nfull_wave + 1)
+                        stamps[13 + RTMI_STAMPS_PER_WAVE * wib] = dg_terms | (dg_refills << 40);  // useful layer terms | refill events
+                        for (int i = 0; i < 6; ++i)
+                            stamps[14 + i + RTMI_STAMPS_PER_WAVE * wib] = dg_sec[i];
                     }
                     break;
                 }
@@ -676,7 +680,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
             T f, fp;
             const bool was_busy = (s.st != ST_DONE);
-            if (stamps) {
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[4] += dg_t1 - dg_t0;
                 const unsigned long long bm = __ballot(was_busy);
                 ++dg_iters;
                 dg_busy += (unsigned long long)__popcll(bm);
@@ -686,9 +692,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 for (int off = 32; off > 0; off >>= 1)
                     terms += __shfl_xor(terms, off, 64);
                 dg_terms += (unsigned long long)terms;
+                dg_t0 = clock64();
             }
             eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
+            if (DIAG && stamps) {
+                dg_t1 = clock64();
+                dg_sec[5] += dg_t1 - dg_t0;
+            }
             lane_advance(s, f, fp);
+            ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
                 if (s.conv)
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
         }
         __syncthreads();
-        if (stamps && j0 == 0 && threadIdx.x == 0)
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[2] = clock64();
 
         // ---- c. travel times in sorted order ----------------------------------------------------
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
         }
         __syncthreads();
-        if (stamps && j0 == 0 && threadIdx.x == 0)
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[3] = clock64();
     }
 
@@ -870,7 +882,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const size_t table = ((size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * elem_bytes + 7) / 8 * 8;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
                          (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
-                         (128 + 128 + 256 + 32) * sizeof(uint32_t);
+                         (128 + 128) * sizeof(uint32_t);
     size_t share = (size_t)160 * 1024 / wg_per_cu;
     int64_t max_slots = share > fixed + 64 * slot_bytes ? (int64_t)((share - fixed) / slot_bytes / 64 * 64) : 64;
     if (max_slots > 8128)
@@ -884,11 +896,11 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     return (int)nblocks;
 }
 
-template <typename T, bool P, bool WT, bool S>
+template <typename T, bool P, bool WT, bool S, bool DIAG = false>
 static hipError_t set_fused_lds_limit()
 {
     // dynamic LDS above 64 KiB needs the opt-in
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -902,6 +914,8 @@ static hipError_t prepare_fused_t()
     if (attr_set)
         return hipSuccess;
     hipError_t e = set_fused_lds_limit<T, false, true, false>();
+    if (e == hipSuccess)
+        e = set_fused_lds_limit<T, false, true, false, true>();
     if (e == hipSuccess)
         e = set_fused_lds_limit<T, true, true, false>();
     if (e == hipSuccess)
@@ -953,6 +967,8 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
         hipLaunchKernelGGL((fused_kernel<T, false, false, true>), grid, block, lds_bytes, stream, a);
     else if (want_p)
         hipLaunchKernelGGL((fused_kernel<T, true, true, false>), grid, block, lds_bytes, stream, a);
+    else if (a.d_stamps)
+        hipLaunchKernelGGL((fused_kernel<T, false, true, false, true>), grid, block, lds_bytes, stream, a);
     else
         hipLaunchKernelGGL((fused_kernel<T, false, true, false>), grid, block, lds_bytes, stream, a);
     return hipGetLastError();

@@ -195,11 +195,11 @@ def test_trace_device_full_c2(rt, O):
     assert np.array_equal(t3.cpu().numpy(), t[np.argsort(off)])
 
 
-@pytest.mark.parametrize("n", [1, 64, 8192, 40001, 300000])
-@pytest.mark.parametrize("wps,refill,tail,retire,seg", [(4, 16, 512, 8, 0), (1, 1, 0, 8, 1), (8, 64, 4096, 21, 0),
-                                                         (5, 7, 100, 1, 1), (3, 16, 0, 0, 0), (4, 8, 0, 21, 1),
-                                                         (2, 4, 64, 16, 1)])
-def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail, retire, seg):
+@pytest.mark.parametrize("n", [1, 64, 8192, 40001, 300000, 1200000])
+@pytest.mark.parametrize("wps,refill,tail,retire,promo", [(4, 16, 256, 8, 10), (1, 1, 0, 8, 3), (8, 64, 4096, 64, 0),
+                                                           (5, 7, 100, 1, 1), (3, 16, 0, 0, 0), (4, 8, 0, 21, 2),
+                                                           (2, 4, 64, 16, 5), (4, 16, 512, 0, 4)])
+def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail, retire, promo):
     """Large source sets take the fused kernel (wave-local sort by layer, lane refill); small ones the plain
     one-lane-per-source kernel.  Same arithmetic per source: bit-identical results under every scheduling
     knob, final ray parameters included, with NaN data, straight rays, interface hits and -999 sources."""
@@ -222,16 +222,16 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail, retire, s
         rt.set_option("refill_min", refill)
         rt.set_option("tail_group", tail)
         rt.set_option("retire_max", retire)
-        rt.set_option("seg_mode", seg)
+        rt.set_option("promote_age", promo)
         t2 = rt.trace_device(dv, dd, do, dz, p_final=p2).cpu().numpy()
         t3 = rt.trace_device(dv, dd, do, dz).cpu().numpy()  # without p_final
     finally:
         rt.set_option("path", 0)
         rt.set_option("waves_per_simd", 4)
         rt.set_option("refill_min", 16)
-        rt.set_option("tail_group", 512)
+        rt.set_option("tail_group", 256)
         rt.set_option("retire_max", 8)
-        rt.set_option("seg_mode", 0)
+        rt.set_option("promote_age", 10)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
     ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
     assert np.array_equal(t2, ref, equal_nan=True)
