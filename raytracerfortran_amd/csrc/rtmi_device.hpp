@@ -22,10 +22,22 @@ enum : int {
     ST_DONE = 5
 };
 
-// The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of (nlayers + 1) doubles.
-#define RTMI_TABLE_ARRAYS 10
+// The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of RTMI_TABLE_STRIDE(nlayers) elements; the pair
+// array HW comes first (16-byte aligned for the fp64 build) and takes two of them.
+#define RTMI_TABLE_ARRAYS 12
+#ifndef RTMI_TERM_GROUP
+#define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
+#endif
+#define RTMI_TABLE_STRIDE(nlayers) ((nlayers) + 2)
+template <typename T>
+struct alignas(2 * sizeof(T)) LayerPair {
+    T hv, vv;
+};
 template <typename T>
 struct LayerTable {
+    LayerPair<T> *HW;  // HW[i] = {HV[i], VV[i]} i < nlayers: what one layer term reads; HW[nul] = {0, 0} is the
+                       // "no layer" entry: its term is exactly 0 for every finite x
+    int nul;           // = nlayers + 1
     T *D;     // D[i]    depth to interface i                       i < nlayers
     T *V;     // V[i]    velocity of layer i                        i <= nlayers
     T *H;     // H[i]    thickness of a fully crossed layer i       i < nlayers
@@ -41,18 +53,20 @@ struct LayerTable {
 template <typename T>
 __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers)
 {
-    const int n1 = nlayers + 1;
+    const int n1 = RTMI_TABLE_STRIDE(nlayers);
     LayerTable<T> t;
-    t.D = lds;
-    t.V = lds + n1;
-    t.H = lds + 2 * n1;
-    t.HV = lds + 3 * n1;
-    t.VV = lds + 4 * n1;
-    t.PS = lds + 5 * n1;
-    t.VMAX = lds + 6 * n1;
-    t.VMI = lds + 7 * n1;
-    t.Q = lds + 8 * n1;
-    t.HVOK = lds + 9 * n1;
+    t.HW = reinterpret_cast<LayerPair<T> *>(lds);
+    t.nul = nlayers + 1;
+    t.D = lds + 2 * n1;
+    t.V = lds + 3 * n1;
+    t.H = lds + 4 * n1;
+    t.HV = lds + 5 * n1;
+    t.VV = lds + 6 * n1;
+    t.PS = lds + 7 * n1;
+    t.VMAX = lds + 8 * n1;
+    t.VMI = lds + 9 * n1;
+    t.Q = lds + 10 * n1;
+    t.HVOK = lds + 11 * n1;
     return t;
 }
 
@@ -85,7 +99,13 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             t.H[i] = h;
             t.HV[i] = h * v;
             t.Q[i] = h / v;
+            t.HW[i].hv = h * v;
+            t.HW[i].vv = v * v;
         }
+    }
+    if (threadIdx.x == 0) {
+        t.HW[t.nul].hv = T(0.0);
+        t.HW[t.nul].vv = T(0.0);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -120,7 +140,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
         const int o = __shfl_xor(v, off, 64);
         v = o > v ? o : v;
     }
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);  // the same in every lane: let loops over it be scalar loops
 }
 
 // whichLayer (:9-32): 1-based index of the first interface strictly below z; nlayers+1 below the
@@ -216,6 +236,60 @@ __device__ __forceinline__ void term_guarded(double w, double a, double hv, doub
     tp = __builtin_fma(__builtin_fma(-s3, q3, hv), r3, q3);
 }
 
+// N independent layer terms, statement by statement side by side: the same operations as N calls of
+// term_guarded, written interleaved so that a wave that has its SIMD to itself (the end of a round) has N
+// dependency chains in flight.
+template <int N>
+__device__ __forceinline__ void term_guarded_n(const double (&w)[N], const double (&a)[N], const double (&hv)[N],
+                                               double (&tf)[N], double (&tp)[N])
+{
+    double y[N], g[N], h[N], e[N], d[N], r[N], q[N], s3[N], r3[N];
+#define RTMI_EACH for (int j = 0; j < N; ++j)
+#pragma unroll
+    RTMI_EACH y[j] = __builtin_amdgcn_rsq(w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = w[j] * y[j];
+#pragma unroll
+    RTMI_EACH h[j] = y[j] * 0.5;
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fma(-h[j], g[j], 0.5);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fma(g[j], e[j], g[j]);
+#pragma unroll
+    RTMI_EACH h[j] = __builtin_fma(h[j], e[j], h[j]);
+#pragma unroll
+    RTMI_EACH d[j] = __builtin_fma(-g[j], g[j], w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fma(d[j], h[j], g[j]);
+#pragma unroll
+    RTMI_EACH d[j] = __builtin_fma(-g[j], g[j], w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fma(d[j], h[j], g[j]);
+#pragma unroll
+    RTMI_EACH r[j] = h[j] + h[j];
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fma(-g[j], r[j], 1.0);
+#pragma unroll
+    RTMI_EACH r[j] = __builtin_fma(r[j], e[j], r[j]);
+#pragma unroll
+    RTMI_EACH q[j] = a[j] * r[j];
+#pragma unroll
+    RTMI_EACH tf[j] = __builtin_fma(__builtin_fma(-g[j], q[j], a[j]), r[j], q[j]);
+#pragma unroll
+    RTMI_EACH s3[j] = (g[j] * g[j]) * g[j];
+#pragma unroll
+    RTMI_EACH r3[j] = (r[j] * r[j]) * r[j];
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fma(-s3[j], r3[j], 1.0);
+#pragma unroll
+    RTMI_EACH r3[j] = __builtin_fma(r3[j], e[j], r3[j]);
+#pragma unroll
+    RTMI_EACH q[j] = hv[j] * r3[j];
+#pragma unroll
+    RTMI_EACH tp[j] = __builtin_fma(__builtin_fma(-s3[j], q[j], hv[j]), r3[j], q[j]);
+#undef RTMI_EACH
+}
+
 // One layer term: tf = (hv*x)/s, tp = hv/((s*s)*s), s = sqrt(1 - xx*vv).  Returns the guard of the fast form.
 template <bool FAST, typename T>
 __device__ __forceinline__ bool layer_term(T xx, T x, T hv, T vv, T &tf, T &tp)
@@ -232,6 +306,34 @@ __device__ __forceinline__ bool layer_term(T xx, T x, T hv, T vv, T &tf, T &tp)
     }
 }
 
+// N layer terms at once (independent chains), added to (sf, sp) in index order.  Returns the fast form's guard.
+template <bool FAST, int N, typename T>
+__device__ __forceinline__ bool add_terms(T xx, T x, const T (&hv)[N], const T (&vv)[N], T &sf, T &sp)
+{
+    T tf[N], tp[N];
+    bool ok = true;
+    if constexpr (FAST && std::is_same<T, double>::value) {
+        T w[N], a[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            w[j] = T(1.0) - xx * vv[j];
+            a[j] = hv[j] * x;
+            ok = ok && w[j] > 1e-60;
+        }
+        term_guarded_n<N>(w, a, hv, tf, tp);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            layer_term<false>(xx, x, hv[j], vv[j], tf[j], tp[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sf = sf + tf[j];
+        sp = sp + tp[j];
+    }
+    return ok;
+}
+
 // costFunc (:184-202) and costFunc_Prime (:206-221) at x for the lane's stack:
 // `nfull` fully crossed layers from the table plus the partial layer (hvl, vvl).
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
@@ -241,41 +343,37 @@ template <bool FAST, typename T>
 __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
                                            T vvl, T R, T &f, T &fp)
 {
+    // No lane is masked inside the loop: a lane whose stack ends before layer i reads the table's "no layer"
+    // entry {0, 0} instead, whose term is (0*x)/sqrt(1) = 0 and 0/1 = 0, and sf + 0 == sf bit for bit (sf is never
+    // -0: it starts at +0).  That keeps the loop free of EXEC masks and branches, so the two chains of a pair are
+    // interleaved by the scheduler.
     const T xx = x * x;
     T sf = T(0.0), sp = T(0.0);
     bool ok = true;
     int i = 0;
-    for (; i + 1 < nfull_wave; i += 2) {
-        T tf0, tp0, tf1, tp1;
-        const bool g0 = layer_term<FAST>(xx, x, t.HV[i], t.VV[i], tf0, tp0);
-        const bool g1 = layer_term<FAST>(xx, x, t.HV[i + 1], t.VV[i + 1], tf1, tp1);
-        if (i < nfull) {
-            sf = sf + tf0;
-            sp = sp + tp0;
-            ok = ok && g0;
+    for (; i + RTMI_TERM_GROUP - 1 < nfull_wave; i += RTMI_TERM_GROUP) {
+        T hv[RTMI_TERM_GROUP], vv[RTMI_TERM_GROUP];
+#pragma unroll
+        for (int j = 0; j < RTMI_TERM_GROUP; ++j) {
+            const LayerPair<T> e = t.HW[i + j < nfull ? i + j : t.nul];
+            hv[j] = e.hv;
+            vv[j] = e.vv;
         }
-        if (i + 1 < nfull) {
-            sf = sf + tf1;
-            sp = sp + tp1;
-            ok = ok && g1;
-        }
+        ok = add_terms<FAST, RTMI_TERM_GROUP>(xx, x, hv, vv, sf, sp) && ok;
     }
-    {
-        // the odd full layer (if any) together with the source's own partial layer
-        T tf0 = T(0.0), tp0 = T(0.0), tfl, tpl;
-        bool g0 = true;
-        const bool odd = i < nfull_wave;  // wave-uniform
-        if (odd)
-            g0 = layer_term<FAST>(xx, x, t.HV[i], t.VV[i], tf0, tp0);
-        const bool gl = layer_term<FAST>(xx, x, hvl, vvl, tfl, tpl);
-        if (odd && i < nfull) {
-            sf = sf + tf0;
-            sp = sp + tp0;
-            ok = ok && g0;
-        }
-        sf = sf + tfl;
-        sp = sp + tpl;
-        ok = ok && gl;
+    for (; i + 1 < nfull_wave; i += 2) {
+        const LayerPair<T> e0 = t.HW[i < nfull ? i : t.nul];
+        const LayerPair<T> e1 = t.HW[i + 1 < nfull ? i + 1 : t.nul];
+        const T hv[2] = {e0.hv, e1.hv}, vv[2] = {e0.vv, e1.vv};
+        ok = add_terms<FAST, 2>(xx, x, hv, vv, sf, sp) && ok;
+    }
+    if (i < nfull_wave) {  // wave-uniform: the odd full layer together with the source's own partial layer
+        const LayerPair<T> e0 = t.HW[i < nfull ? i : t.nul];
+        const T hv[2] = {e0.hv, hvl}, vv[2] = {e0.vv, vvl};
+        ok = add_terms<FAST, 2>(xx, x, hv, vv, sf, sp) && ok;
+    } else {
+        const T hv[1] = {hvl}, vv[1] = {vvl};
+        ok = add_terms<FAST, 1>(xx, x, hv, vv, sf, sp) && ok;
     }
     f = R - sf;
     fp = -sp;

@@ -98,7 +98,7 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
 template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS>
 __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
 {
-    extern __shared__ double lds_raw[];  // 8-byte aligned storage for either element type
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     const int nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
@@ -186,7 +186,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
-    extern __shared__ double lds_raw[];  // 8-byte aligned storage for either element type
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     const int nwib = blockDim.x >> 6;
     const int slots = a.slots;
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
-                                  ((size_t)RTMI_TABLE_ARRAYS * (a.nlayers + 1) * sizeof(T) + 7) / 8 * 8);  // offset }
+                                  ((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(a.nlayers) * sizeof(T) + 15) / 16 * 16);  // offset }
     T *rz = rR + slots;                                  // depth             } sorted by descending layer
     T *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
@@ -815,7 +815,7 @@ static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &a, int nmodels, int 
                                  hipStream_t stream)
 {
     using namespace rtmi;
-    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * sizeof(T);
+    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(max_nlayers) * sizeof(T);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
@@ -879,7 +879,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = ((size_t)RTMI_TABLE_ARRAYS * (max_nlayers + 1) * elem_bytes + 7) / 8 * 8;
+    const size_t table = ((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(max_nlayers) * elem_bytes + 15) / 16 * 16;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
                          (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
                          (128 + 128) * sizeof(uint32_t);
