@@ -10,6 +10,8 @@ lib = rt.load_library(); rt.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 if len(sys.argv) > 2:
     rt.set_option("promote_age", int(sys.argv[2]))
+fine = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # 0: phase and per-wave clocks only (undisturbed timeline)
+rt.set_option("diag_fine", fine)
 v, d, off, dep = bench.c2_workload(n)
 dev = "cuda"
 dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
@@ -54,6 +56,13 @@ print("waves per workgroup:", used.sum(1).mean())
 print("queue seen empty (first wave)  mean %.0f   (last wave) mean %.0f" % (np.nanmin(dry, 1).mean(), np.nanmax(dry, 1).mean()))
 print("wave finished        (first)   mean %.0f   (last)      mean %.0f" % (np.nanmin(fin, 1).mean(), np.nanmax(fin, 1).mean()))
 print("mean over waves of (finish - empty): %.0f ticks" % np.nanmean(fin - dry))
+if not fine:
+    print("wave:   " + " ".join("%7d" % w for w in range(16)))
+    print("dry:    " + " ".join("%7.0f" % x for x in np.nanmean(dry, 0)))
+    print("finish: " + " ".join("%7.0f" % x for x in np.nanmean(fin, 0)))
+    sub = full[:, 4:7].astype(float) - full[:, 0:1]
+    print("phase a cumulative:", np.round(sub.mean(0)))
+    sys.exit(0)
 iters = wv[:, :, 2][used].sum(); busy = wv[:, :, 3][used].sum(); trips = wv[:, :, 4][used].sum()
 terms = (wv[:, :, 5][used] & ((1 << 40) - 1)).sum(); refills = (wv[:, :, 5][used] >> 40).sum()
 print("solve loop: %d wave-trips, live lanes per trip %.1f / 64, layer-loop length per trip %.2f" % (iters, busy / iters, trips / iters))

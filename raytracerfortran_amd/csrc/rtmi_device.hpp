@@ -24,7 +24,8 @@ enum : int {
 
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of RTMI_TABLE_STRIDE(nlayers) elements; the pair
 // array HW comes first (16-byte aligned for the fp64 build) and takes two of them.
-#define RTMI_TABLE_ARRAYS 12
+#define RTMI_TABLE_ARRAYS 15
+#define RTMI_TRIP_CLASSES 7  // classes of trip_class (the fused kernel's solve order puts the Newton-only class after them)
 #ifndef RTMI_TERM_GROUP
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
 #endif
@@ -47,7 +48,11 @@ struct LayerTable {
     T *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
     T *VMI;   // VMI[i]  1/VMAX[i]                                  i <= nlayers
     T *Q;     // scratch H[i]/V[i]
-    T *HVOK;  // HVOK[i] 1.0 if HV[0..i] are all 0 or of moderate magnitude (fast-path guard), else 0.0
+    T *PA;    // } scheduling hint only (trip_class): the offset the rest of the stack covers when the ray runs
+    T *PC;    // } critical in its fastest layer, PA[il] + hl * PC[il], and that layer's thickness PH[il] (0: it
+    T *PH;    // } is the source's own layer, thickness hl)                             1 <= il <= nlayers
+    T *HVOK;  // HVOK[i] 1.0 if H and H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
+              // (fast-path guards), else 0.0
 };
 
 template <typename T>
@@ -67,6 +72,9 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers)
     t.VMI = lds + 9 * n1;
     t.Q = lds + 10 * n1;
     t.HVOK = lds + 11 * n1;
+    t.PA = lds + 12 * n1;
+    t.PC = lds + 13 * n1;
+    t.PH = lds + 14 * n1;
     return t;
 }
 
@@ -79,12 +87,19 @@ __device__ __forceinline__ bool mag_ok(double v)
     return v == 0.0 || (a > 1e-30 && a < 1e30);
 }
 
+__device__ __forceinline__ bool mag_nz(float) { return true; }
+__device__ __forceinline__ bool mag_nz(double v)  // as mag_ok, zero excluded: safe as a factor of a denominator
+{
+    const double a = fabs(v);
+    return a > 1e-30 && a < 1e30;
+}
+
 // Derive the table of one model (whole workgroup; ends with a barrier).  Roundings are the reference's:
 //   H(i) = depths(i) - depths(i-1)            InsertLayer :67
 //   (H*V) and (V*V) as separate products      costFunc :195, costFunc_Prime :214-219
 //   sum(depths/vp) left to right              GetPTime :112
 //   1/maxval(vp)                              :142, :148, :299, :388
-template <typename T>
+template <bool WITH_HINT = false, typename T>
 __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__restrict__ vels,
                                             const T *__restrict__ depths, int nlayers)
 {
@@ -106,12 +121,15 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
     if (threadIdx.x == 0) {
         t.HW[t.nul].hv = T(0.0);
         t.HW[t.nul].vv = T(0.0);
+        t.H[t.nul] = T(0.0);
+        t.V[t.nul] = T(1.0);
+        t.VV[t.nul] = T(0.0);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         T s = t.Q[0];
         T m = t.V[0];
-        bool ok = mag_ok(t.HV[0]);
+        bool ok = mag_ok(t.HV[0]) && mag_ok(t.H[0]) && mag_nz(m);
         t.PS[0] = s;
         t.VMAX[0] = m;
         t.HVOK[0] = ok ? T(1.0) : T(0.0);
@@ -122,7 +140,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             if (i < nlayers) {
                 s = s + t.Q[i];
                 t.PS[i] = s;
-                ok = ok && mag_ok(t.HV[i]);
+                ok = ok && mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v);
                 t.HVOK[i] = ok ? T(1.0) : T(0.0);
             }
         }
@@ -130,7 +148,54 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
     __syncthreads();
     for (int i = threadIdx.x; i <= nlayers; i += blockDim.x)
         t.VMI[i] = T(1.0) / t.VMAX[i];
+    if constexpr (WITH_HINT) {
+        // Where the fused kernel's solve order comes from (trip_class): a ray that needs many evaluations is one
+        // that runs almost horizontally in the fastest layer j of its stack (p close to 1/vmax).  There the
+        // offset is  R ~ A + H_j / sqrt(1 - (p vmax)^2)  with A the offset covered by the other layers at
+        // p = 1/vmax, so (R - A) / H_j tells how close to critical the solution lies.  Single precision: this
+        // only orders the work, no result depends on it.
+        for (int il = 1 + (int)threadIdx.x; il <= nlayers; il += blockDim.x) {
+            const float vmax = (float)t.VMAX[il];
+            int j = 0;
+            while (j < il && (float)t.V[j] != vmax)
+                ++j;  // first layer of the stack (own layer = il included) with the maximum velocity
+            float a = 0.0f, c = 0.0f;
+            for (int i = 0; i <= il; ++i) {
+                if (i == j)
+                    continue;
+                const float pv = fminf((float)t.V[i] / vmax, 0.999999f);
+                const float r = pv * __frsqrt_rn(1.0f - pv * pv);  // tan of the ray angle in layer i at p = 1/vmax
+                if (i < il)
+                    a += (float)t.H[i] * r;
+                else
+                    c = r;
+            }
+            t.PA[il] = (T)a;
+            t.PC[il] = (T)c;
+            t.PH[il] = j < il ? t.H[j] : T(0.0);
+        }
+    }
     __syncthreads();
+}
+
+// Class 0..6 of a source that starts with the bisection, by the evaluations it is expected to take (about
+// 5.5 + 2 log2((R - A) / H_j), see stage_model): 0 = more than ~21, then steps of about two down to 6 = at most
+// ~10.  A scheduling hint: it decides when the source is handed to a lane, nothing else.
+template <typename T>
+__device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T z)
+{
+    const T hl = z - t.D[il - 1];
+    const T num = R - (t.PA[il] + hl * t.PC[il]);
+    const T hj = t.PH[il];
+    const T den = hj > T(0.0) ? hj : hl;
+    int c = RTMI_TRIP_CLASSES - 1;
+    c -= (num > den * T(4.76));    // 2^2.25
+    c -= (num > den * T(9.51));    // 2^3.25
+    c -= (num > den * T(19.0));    // 2^4.25
+    c -= (num > den * T(38.1));    // 2^5.25
+    c -= (num > den * T(90.5));    // 2^6.5
+    c -= (num > den * T(256.0));   // 2^8
+    return c;
 }
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -190,7 +255,7 @@ __device__ __forceinline__ double sqrt_guarded(double w)  // w in (1e-60, 1]
     return g;
 }
 
-__device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-90, 1], n == 0 or |n| in (1e-60, 1e60)
+__device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-90, 1e30), n == 0 or |n| in (1e-60, 1e60)
 {
     double r = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, r, 1.0);
@@ -469,12 +534,16 @@ __device__ __forceinline__ void lane_start(Lane<T> &s, T p0)
 // different states almost always, so a branchy dispatch executes every state's body on every trip;
 // the select form shares the common pieces (one quotient, one `check_x`, one Newton update).
 // Every value is computed by the same operation on the same operands as in the reference.
-template <typename T>
+// MODE tells what the caller knows about the states present, so that the other states' selects fold away:
+// the fused kernel evaluates ST_INIT in a pass of its own and never meets it in the solve loop.
+enum : int { ADV_ANY = 0, ADV_INIT_ONLY = 1, ADV_NO_INIT = 2 };
+template <int MODE = ADV_ANY, typename T>
 __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
-    const bool isI = (st == ST_INIT), isB0 = (st == ST_BIS0), isB = (st == ST_BIS), isN = (st == ST_NEWTON),
-               isF = (st == ST_FINAL);
+    const bool isI = MODE == ADV_INIT_ONLY ? true : (MODE == ADV_NO_INIT ? false : st == ST_INIT);
+    const bool isB0 = MODE != ADV_INIT_ONLY && (st == ST_BIS0), isB = MODE != ADV_INIT_ONLY && (st == ST_BIS),
+               isN = MODE != ADV_INIT_ONLY && (st == ST_NEWTON), isF = MODE != ADV_INIT_ONLY && (st == ST_FINAL);
     // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294): same operands, one divide
     const T q = f / fp;
     const bool neg = f < T(0.0);
@@ -530,22 +599,85 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
                                                         : (n_conv || isF) ? ST_DONE : st;
 }
 
-// Travel time for a known ray parameter (:156, :165-166).  Wave-uniform loop.
-template <typename T>
-__device__ __forceinline__ T travel_time(const LayerTable<T> &t, T p, int nfull, int nfull_wave, int il,
-                                              T z)
+// Travel time for a known ray parameter (:156, :165-166): tt = sum H_i / (V_i * sqrt(1 - p^2 V_i^2)) over the
+// fully crossed layers, then the partial layer.  Wave-uniform loop, two layers side by side, no lane masked: a
+// lane whose stack has ended reads the "no layer" entry (H = 0, V = 1, VV = 0), whose term is 0 / 1.
+// FAST: guarded sqrt and divide (same bits as the plain operators inside the guards); returns the guard.
+template <bool FAST, typename T>
+__device__ __forceinline__ bool travel_time_terms(const LayerTable<T> &t, T p, int nfull, int nfull_wave, int il,
+                                                  T hl, T &tt_out)
 {
     const T pp = p * p;
     T tt = T(0.0);
-    for (int i = 0; i < nfull_wave; ++i) {
-        const T cosv = sqrt(T(1.0) - pp * t.VV[i]);
-        const T ti = t.H[i] / (t.V[i] * cosv);
-        if (i < nfull)
-            tt = tt + ti;
+    bool ok = true;
+    auto pair = [&](T h0, T v0, T vv0, T h1, T v1, T vv1) {
+        const T w0 = T(1.0) - pp * vv0, w1 = T(1.0) - pp * vv1;
+        T t0, t1;
+        if constexpr (FAST && std::is_same<T, double>::value) {
+            // sqrt_guarded and div_guarded of both terms, statement by statement side by side
+            const double y0 = __builtin_amdgcn_rsq(w0), y1 = __builtin_amdgcn_rsq(w1);
+            double g0 = w0 * y0, g1 = w1 * y1;
+            double k0 = y0 * 0.5, k1 = y1 * 0.5;
+            const double e0 = __builtin_fma(-k0, g0, 0.5), e1 = __builtin_fma(-k1, g1, 0.5);
+            g0 = __builtin_fma(g0, e0, g0);
+            g1 = __builtin_fma(g1, e1, g1);
+            k0 = __builtin_fma(k0, e0, k0);
+            k1 = __builtin_fma(k1, e1, k1);
+            double d0 = __builtin_fma(-g0, g0, w0), d1 = __builtin_fma(-g1, g1, w1);
+            g0 = __builtin_fma(d0, k0, g0);
+            g1 = __builtin_fma(d1, k1, g1);
+            d0 = __builtin_fma(-g0, g0, w0);
+            d1 = __builtin_fma(-g1, g1, w1);
+            g0 = __builtin_fma(d0, k0, g0);  // cos_0
+            g1 = __builtin_fma(d1, k1, g1);  // cos_1
+            const double n0 = v0 * g0, n1 = v1 * g1;  // denominators V*cos
+            double r0 = __builtin_amdgcn_rcp(n0), r1 = __builtin_amdgcn_rcp(n1);
+            double c0 = __builtin_fma(-n0, r0, 1.0), c1 = __builtin_fma(-n1, r1, 1.0);
+            r0 = __builtin_fma(r0, c0, r0);
+            r1 = __builtin_fma(r1, c1, r1);
+            c0 = __builtin_fma(-n0, r0, 1.0);
+            c1 = __builtin_fma(-n1, r1, 1.0);
+            r0 = __builtin_fma(r0, c0, r0);
+            r1 = __builtin_fma(r1, c1, r1);
+            const double q0 = h0 * r0, q1 = h1 * r1;
+            t0 = __builtin_fma(__builtin_fma(-n0, q0, h0), r0, q0);
+            t1 = __builtin_fma(__builtin_fma(-n1, q1, h1), r1, q1);
+            ok = ok && w0 > 1e-60 && w1 > 1e-60;
+        } else {
+            t0 = h0 / (v0 * sqrt(w0));
+            t1 = h1 / (v1 * sqrt(w1));
+        }
+        tt = tt + t0;
+        tt = tt + t1;
+    };
+    int i = 0;
+    for (; i + 1 < nfull_wave; i += 2) {
+        const int j0 = i < nfull ? i : t.nul, j1 = i + 1 < nfull ? i + 1 : t.nul;
+        pair(t.H[j0], t.V[j0], t.VV[j0], t.H[j1], t.V[j1], t.VV[j1]);
     }
+    // the odd full layer (or "no layer") together with the source's own partial layer
+    const int j0 = (i < nfull_wave && i < nfull) ? i : t.nul;
+    pair(t.H[j0], t.V[j0], t.VV[j0], hl, t.V[il], t.VV[il]);
+    tt_out = tt;
+    return ok;
+}
+
+// `tab_ok`: the stack's H and V are 0 / of moderate magnitude (HVOK of the deepest full layer and the source's
+// own layer); `valid`: the lane carries a source (other lanes never veto the fast path).
+template <typename T>
+__device__ __forceinline__ T travel_time(const LayerTable<T> &t, T p, int nfull, int nfull_wave, int il, T z,
+                                         bool valid = true)
+{
     const T hl = z - t.D[il - 1];
-    const T cosv = sqrt(T(1.0) - pp * t.VV[il]);
-    tt = tt + hl / (t.V[il] * cosv);
+    T tt;
+    if constexpr (std::is_same<T, double>::value) {
+        const bool tab_ok = (t.HVOK[il - 1] != T(0.0)) && mag_ok(hl) && mag_nz(t.V[il]);
+        const bool ok = travel_time_terms<true>(t, p, nfull, nfull_wave, il, hl, tt) && tab_ok;
+        if (__any(valid && !ok))
+            travel_time_terms<false>(t, p, nfull, nfull_wave, il, hl, tt);
+    } else {
+        travel_time_terms<false>(t, p, nfull, nfull_wave, il, hl, tt);
+    }
     return tt;
 }
 

@@ -83,7 +83,7 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
         lane_advance(s, f, fp);
     }
 
-    T tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z);
+    T tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z, active);
     if (!s.conv)
         tt = -T(999.0);
     p_out = s.x;
@@ -174,7 +174,10 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 }
 
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
-#define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..28
+#define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..23 (nl <= 1025)
+#define RTMI_RK_NL_MASK 0x7FFu
+#define RTMI_RK_CLASS_SHIFT 24        // rk: class of the solve order in bits 24..26 (0 = most evaluations expected)
+#define RTMI_RK_CLASSES 8
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
 #define RTMI_RK_DONE 0x40000000u      // rk: finished by its first evaluation (or p0 is NaN): not in the solve order
@@ -195,11 +198,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
     const LayerTable<T> t = carve_table(lds, a.nlayers);
-    stage_model(t, a.d_vels, a.d_depths, a.nlayers);
+    stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index: scalar
     const int nwib = blockDim.x >> 6;
     const int slots = a.slots;
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
@@ -223,8 +226,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     volatile lds_int *pl_ready = (volatile lds_int *)(pl_state + RTMI_POOL);
     volatile lds_int *pl_ctl = pl_ready + RTMI_POOL;            // [0] tail (reserved), [1] head (claimed), [2] local waves still solving
     // exact solve order: per 64-slot chunk, counts and first order[] positions of the two classes
-    uint32_t *ch_cnt = reinterpret_cast<uint32_t *>(pl_state + 2 * RTMI_POOL + 4);  // [128] long | short << 16
-    uint32_t *ch_start = ch_cnt + 128;                          // [128] long | short << 16
+    uint32_t *cls_base = reinterpret_cast<uint32_t *>(pl_state + 2 * RTMI_POOL + 4);  // [9] first order[] position of a class
+    // per 64-slot chunk, counts and first positions of the eight classes as 16-bit fields of two 64-bit words
+    // (classes 0-3, 4-7); they live in `hist`, which is free once the records are in their slots
+    unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [2][128]
+    unsigned long long *ch_start = ch_cnt + 256;                                  // [2][128]
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     // Diagnostic phase clocks (NULL in normal runs): per workgroup {start, after sort, after solve, after time}
     // of its FIRST round, in shader-clock ticks.  The stamps go to a buffer nothing else reads.
     unsigned long long *stamps = (DIAG && a.d_stamps) ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
+    const bool fine = DIAG && stamps && a.diag_fine;  // per-trip clocks and counters (they slow the loop down by a quarter)
     for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
         // ---- a. load + workgroup-local STABLE counting sort ------------------------------------
         // No atomics: lane b of each wave counts the wave's records of bin b in a register (one
@@ -244,13 +251,21 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             stamps[0] = clock64();
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t mycnt = 0;
+        // the next chunk's depths are requested before this chunk's are used (one global round trip in flight)
+        auto depth_of = [&](int c) {
+            const int64_t chunk = b + (j0 + c) * nblocks;
+            const int64_t k = chunk * 64 + lane;
+            return (c < CH && chunk < nchunks && k < a.nsrc) ? a.d_src_depth[k] : T(0.0);
+        };
+        T z_next = depth_of(wib);
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const T z = valid ? a.d_src_depth[k] : T(0.0);
+            const T z = z_next;
+            z_next = depth_of(c + nwib);
             int nl = which_layer(t, a.nlayers, z);
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
@@ -301,12 +316,22 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         }
         __syncthreads();
         uint32_t woff = hist[wib * 64 + lane];  // lane b: next free slot of bin b for this wave
+        auto offset_of = [&](int c) {
+            const int64_t chunk = b + (j0 + c) * nblocks;
+            const int64_t k = chunk * 64 + lane;
+            return (c < CH && chunk < nchunks && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
+        };
+        T R_next = offset_of(wib);
+        z_next = depth_of(wib);
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
+            const T R = R_next, z = z_next;
+            R_next = offset_of(c + nwib);
+            z_next = depth_of(c + nwib);
             const int nl = valid ? (int)tnl[c * 64 + lane] : 1;
             const int bin = bin_of(nl, nl_max);
             uint32_t pos = 0;
@@ -322,8 +347,6 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 todo &= ~grp;
             }
             if (valid) {
-                const T R = a.d_src_offset[k];
-                const T z = a.d_src_depth[k];
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
                     const T tt = sqrt(z * z + R * R) / t.V[0];
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[5] = clock64();  // records in their slots, p0 computed
-        const int nq = (int)qctl[1];
+        const int nq = __builtin_amdgcn_readfirstlane((int)qctl[1]);  // wave-uniform values are kept in SGPRs
 
         // ---- a2. first evaluation of every record, in sorted order (one layer count per wave) -------
         // GetPTime's branch (:136-153) is taken here, at full lane occupancy.  It also tells which
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const bool valid = q < nq;
             Lane<T> s;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
             const T p0 = valid ? rp[q] : T(0.0);
             lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
             lane_start(s, p0);
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             T f, fp;
             eval_f_fp(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
             if (live)
-                lane_advance(s, f, fp);
+                lane_advance<ADV_INIT_ONLY>(s, f, fp);
             if (valid) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
@@ -381,7 +404,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 } else {
                     rp[q] = s.xe;  // BIS0: 1e-10; NEWTON: the first Newton iterate (x == xe)
                     if (s.st != ST_BIS0)
-                        k2 |= RTMI_RK_SHORT;
+                        k2 |= RTMI_RK_SHORT | ((uint32_t)(RTMI_RK_CLASSES - 1) << RTMI_RK_CLASS_SHIFT);
+                    else
+                        k2 |= (uint32_t)trip_class(t, nl - 1, s.R, rz[q]) << RTMI_RK_CLASS_SHIFT;
                 }
                 rk[q] = k2;
             }
@@ -391,56 +416,76 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             stamps[6] = clock64();  // first evaluation done
 
         // ---- a3. exact solve order ----------------------------------------------------------------------
-        // order[] = the long class, then the short class, each in slot order (= descending layer index), built
-        // from per-chunk ballots (deterministic).
+        // order[] = class 0, class 1, ... (most expected evaluations first; the short class last), each in slot
+        // order (= descending layer index), built from per-chunk ballots (deterministic).  Longest first is
+        // what keeps the end of the round short: the last records handed out are the cheapest ones.
         const int nchq = (nq + 63) >> 6;  // <= 127
         for (int c = wib; c < nchq; c += nwib) {
             const int q = c * 64 + lane;
             const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
             const bool todo = !(key & RTMI_RK_DONE);
-            const bool sht = todo && (key & RTMI_RK_SHORT);
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(todo && !sht)) | ((uint32_t)__popcll(__ballot(sht)) << 16);
-            if (lane == 0)
-                ch_cnt[c] = cnt;
+            const int cls = (int)((key >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
+            unsigned long long w0 = 0, w1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w0 |= (unsigned long long)__popcll(__ballot(todo && cls == k)) << (16 * k);
+                w1 |= (unsigned long long)__popcll(__ballot(todo && cls == k + 4)) << (16 * k);
+            }
+            if (lane == 0) {
+                ch_cnt[c] = w0;
+                ch_cnt[128 + c] = w1;
+            }
         }
         __syncthreads();
         if (wib == 0) {
-            // lane l owns chunks 2l and 2l+1: exclusive prefix of the two counts (16-bit fields, no carry: <= 8128)
+            // lane l owns chunks 2l and 2l+1: exclusive prefix of the counts (16-bit fields, no carry: <= 8128)
             const int c0 = 2 * lane, c1 = 2 * lane + 1;
-            const uint32_t n0 = c0 < nchq ? ch_cnt[c0] : 0u, n1 = c1 < nchq ? ch_cnt[c1] : 0u;
-            uint32_t in_n = n0 + n1;
+            unsigned long long tot[2];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t on = __shfl_up(in_n, off, 64);
-                if (lane >= off)
-                    in_n += on;
+            for (int h = 0; h < 2; ++h) {
+                const unsigned long long n0 = c0 < nchq ? ch_cnt[128 * h + c0] : 0ull;
+                const unsigned long long n1 = c1 < nchq ? ch_cnt[128 * h + c1] : 0ull;
+                unsigned long long in_n = n0 + n1;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned long long on = __shfl_up(in_n, off, 64);
+                    if (lane >= off)
+                        in_n += on;
+                }
+                tot[h] = __shfl(in_n, 63, 64);
+                const unsigned long long ex_n = in_n - (n0 + n1);
+                if (c0 < nchq)
+                    ch_start[128 * h + c0] = ex_n;
+                if (c1 < nchq)
+                    ch_start[128 * h + c1] = ex_n + n0;
             }
-            const uint32_t tot_n = __shfl(in_n, 63, 64);
-            const uint32_t ex_n = in_n - (n0 + n1);
-            if (c0 < nchq)
-                ch_start[c0] = ex_n;
-            if (c1 < nchq)
-                ch_start[c1] = ex_n + n0;
             if (lane == 0) {
-                qctl[2] = tot_n & 0xFFFFu;  // n_long
-                qctl[3] = tot_n >> 16;      // n_short
+                uint32_t run = 0;
+                for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
+                    cls_base[k] = run;
+                    run += (uint32_t)((tot[k >> 2] >> (16 * (k & 3))) & 0xFFFFull);
+                }
+                cls_base[RTMI_RK_CLASSES] = run;  // records that need the solve loop
             }
         }
         __syncthreads();
-        const int n_long = (int)qctl[2];
-        const int n_todo = n_long + (int)qctl[3];  // records that need the solve loop
+        const int n_todo = __builtin_amdgcn_readfirstlane((int)cls_base[RTMI_RK_CLASSES]);
         for (int c = wib; c < nchq; c += nwib) {
             const int q = c * 64 + lane;
             const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
             const bool todo = !(key & RTMI_RK_DONE);
-            const bool sht = todo && (key & RTMI_RK_SHORT);
-            const bool lng = todo && !sht;
-            const unsigned long long bl = __ballot(lng), bs = __ballot(sht);
-            const uint32_t st = ch_start[c];
-            if (lng)
-                order[(st & 0xFFFFu) + __popcll(bl & lt_mask)] = (uint16_t)q;
-            if (sht)
-                order[n_long + (st >> 16) + __popcll(bs & lt_mask)] = (uint16_t)q;
+            const int cls = (int)((key >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
+                const unsigned long long bk = __ballot(todo && cls == k);
+                if (cls == k)
+                    mine = bk;
+            }
+            if (todo) {
+                const uint32_t st = (uint32_t)((ch_start[128 * (cls >> 2) + c] >> (16 * (cls & 3))) & 0xFFFFull);
+                order[cls_base[cls] + st + (uint32_t)__popcll(mine & lt_mask)] = (uint16_t)q;
+            }
         }
         __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
@@ -474,6 +519,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         const bool split = nwib > 4 && n_todo >= (int)blockDim.x && (a.retire_max > 0 || promote_age > 0);
         const bool local = split && wib >= 4;
         const bool express = split && wib < 4;
+        // this wave stops taking fresh records once fewer than stop_below remain queued: with express_stop the
+        // express waves leave the last (short) records to the local waves and keep to the long sources handed to
+        // them; the local wave groups (or, without express_stop, all groups) stop one after the other
+        const int express_stop = split ? (a.express_stop < n_todo / 3 ? a.express_stop : n_todo / 3) : 0;
+        const int stop_below = express_stop > 0 ? (wib < 4 ? express_stop : ((wib >> 2) - 1) * tail_group)
+                                                : (wib >> 2) * tail_group;
         bool left = false;  // (local) this wave has signed off from rg[3]
         int spins = 0;
         int nfull_wave = 0;
@@ -481,12 +532,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0, dg_refills = 0, dg_t0 = 0, dg_t1 = 0;
         unsigned long long dg_sec[6] = {0, 0, 0, 0, 0, 0};  // ticks in: tail check, hand-over, adoption, refill, wave max + exit test, evaluation
         for (;;) {
-            if (DIAG && stamps)
+            if (DIAG && fine)
                 dg_t0 = clock64();
             unsigned long long idle = __ballot(s.st == ST_DONE);
             int nidle = __popcll(idle);
             bool changed = false;
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[0] += dg_t1 - dg_t0;
                 dg_t0 = dg_t1;
@@ -538,13 +589,14 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
             }
 
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[1] += dg_t1 - dg_t0;
                 dg_t0 = dg_t1;
             }
             // -- express waves: adopt handed-over sources into idle lanes ----------------------------------
-            if (express && nidle > 0 && pl_ctl[1] < pl_ctl[0]) {
+            if (express && nidle > 0 &&
+                __builtin_amdgcn_readfirstlane(pl_ctl[1]) < __builtin_amdgcn_readfirstlane(pl_ctl[0])) {
                 int base = 0, take = 0;
                 if (lane == 0) {
                     int head = pl_ctl[1];
@@ -582,7 +634,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         pl_ready[e] = -gen;  // slot read: free for the next tenant
                         const uint32_t key = rk[slot];
-                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
                         const T keep_xe = s.xe, keep_x = s.x, keep_xb = s.xb, keep_dx = s.dx;
                         lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
                         s.xe = keep_xe;
@@ -600,7 +652,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
             }
 
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[2] += dg_t1 - dg_t0;
                 dg_t0 = dg_t1;
@@ -608,8 +660,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             // -- fresh records from the queue -----------------------------------------------------------------
             // End-game concentration: the last records of the queue go to the first waves only (wave group g =
             // wib / 4 stops refilling once fewer than g * tail_group records remain).
-            if (!exhausted && nidle >= a.refill_min && tail_group > 0 && wib >= 4 &&
-                n_todo - (int)qctl[0] < (wib >> 2) * tail_group) {
+            if (!exhausted && nidle >= a.refill_min && stop_below > 0 &&
+                n_todo - __builtin_amdgcn_readfirstlane((int)qctl[0]) < stop_below) {
                 exhausted = true;
                 if (DIAG && stamps && j0 == 0 && lane == 0)
                     stamps[8 + RTMI_STAMPS_PER_WAVE * wib] = clock64();
@@ -629,7 +681,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         // long class, then short class, both in descending layer order
                         slot = (int)order[qi];
                         const uint32_t key = rk[slot];
-                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu);
+                        const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
                         lane_setup(s, t, nl - 1, rR[slot], rz[slot]);
                         lane_start(s, rp[slot]);
                         if (key & RTMI_RK_SHORT) {
@@ -643,7 +695,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
                 changed = true;
             }
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[3] += dg_t1 - dg_t0;
                 dg_t0 = dg_t1;
@@ -660,7 +712,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
                 if (exhausted && express) {
                     // stay until every local wave has signed off and the ring is drained
-                    finished = (pl_ctl[2] <= 0 && pl_ctl[1] >= pl_ctl[0]) || ++spins > (1 << 24);
+                    finished = (__builtin_amdgcn_readfirstlane(pl_ctl[2]) <= 0 &&
+                                __builtin_amdgcn_readfirstlane(pl_ctl[1]) >= __builtin_amdgcn_readfirstlane(pl_ctl[0])) ||
+                               ++spins > (1 << 24);
                     if (!finished)
                         __builtin_amdgcn_s_sleep(4);
                 }
@@ -680,7 +734,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
             T f, fp;
             const bool was_busy = (s.st != ST_DONE);
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[4] += dg_t1 - dg_t0;
                 const unsigned long long bm = __ballot(was_busy);
@@ -695,11 +749,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 dg_t0 = clock64();
             }
             eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
-            if (DIAG && stamps) {
+            if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
             }
-            lane_advance(s, f, fp);
+            lane_advance<ADV_NO_INIT>(s, f, fp);
             ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
@@ -716,11 +770,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const int q = q0 + lane;
             const bool valid = q < nq;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & 0xFFFFu) - 1;
+            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
             const T p = valid ? rp[q] : T(0.0);
             const T z = valid ? rz[q] : T(1.0);
             const int nfw = wave_max_i32(valid ? il : 0);
-            T tt = travel_time(t, p, il, nfw, il, z);
+            T tt = travel_time(t, p, il, nfw, il, z, valid);
             if (!(key & RTMI_RK_CONV))
                 tt = -T(999.0);
             if (valid) {

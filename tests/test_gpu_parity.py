@@ -272,7 +272,7 @@ def test_fast_math_equals_ieee(rt):
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 1 << 24
     total_s = total_d = total_t = 0
-    for trial in range(6):
+    for trial in range(7):
         u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         e = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if trial == 0:      # solver-like: w in (0, 1], numerators ~ H*V*p, denominators s and s^3
@@ -297,14 +297,18 @@ def test_fast_math_equals_ieee(rt):
             hv = (50.0 + 3000.0 * e) * (1500.0 + 8500.0 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
             den = hv
             num = hv * (pv / 6000.0)
-        else:               # near-critical layers: w down to 1e-12
+        elif trial == 5:    # near-critical layers: w down to 1e-12
             w = torch.exp(-27.0 * u)
             den = 1e5 + 1e7 * e
             num = den * 1e-4 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        else:               # the time pass: H / (V cos) with the whole guarded range of V cos, H = 0 included
+            w = torch.exp(-138.0 * u)
+            den = torch.exp(207.0 * (e - 2.0 / 3.0))          # 1e-60 .. 1e30
+            num = torch.where(u > 0.95, torch.zeros_like(u), torch.exp(138.0 * (u - 0.5)) * torch.sign(e - 0.2))
         bs, bd, bt = raymod.selftest_fastmath(w.contiguous(), num.contiguous(), den.contiguous())
         total_s += bs
         total_d += bd
-        if trial >= 3:      # the layer term is only ever fed solver-shaped operands (guards: w in (1e-60, 1])
+        if 3 <= trial <= 5:  # the layer term is only ever fed solver-shaped operands (guards: w in (1e-60, 1])
             total_t += bt
     assert (total_s, total_d, total_t) == (0, 0, 0)
 
