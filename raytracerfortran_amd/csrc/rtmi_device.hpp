@@ -240,7 +240,7 @@ __device__ __forceinline__ int which_layer(const LayerTable<T> &t, int nlayers, 
 // operands of real solves and on random operands).  eval_f_fp only takes them when every operand
 // of the wave is inside the guard, and otherwise re-evaluates with the plain operators.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sqrt_guarded(double w)  // w in (1e-60, 1]
+__device__ __forceinline__ double sqrt_guarded(double w)  // w in (1e-60, 1e60)
 {
     const double y = __builtin_amdgcn_rsq(w);
     double g = w * y;
@@ -494,14 +494,29 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
 
 // GetPTime head (:112-133): the starting ray parameter.  Returns NaN when the reference would loop
 // forever (NaN/Inf source data): such a source is reported as -999.
-template <typename T>
-__device__ __forceinline__ T initial_p0(const LayerTable<T> &t, int il, T R, T z)
+// FAST: the three divides and the square root in their guarded forms (same bits inside the guards); `ok`
+// returns whether every operand was inside them.
+template <bool FAST, typename T>
+__device__ __forceinline__ T initial_p0_impl(const LayerTable<T> &t, int il, T R, T z, bool &ok)
 {
     const T vl = t.V[il];
     const T hl = z - t.D[il - 1];
-    const T c_harmonic = z / (t.PS[il - 1] + hl / vl);
-    const T cos_t = z / sqrt(R * R + z * z);
-    T p0 = cos_t / c_harmonic;
+    const T rr = R * R + z * z;
+    T p0;
+    if constexpr (FAST && std::is_same<T, double>::value) {
+        const T tv = t.PS[il - 1] + div_guarded(hl, vl);  // vertical time above the source
+        const T c_harmonic = div_guarded(z, tv);
+        const T cos_t = div_guarded(z, sqrt_guarded(rr));
+        p0 = div_guarded(cos_t, c_harmonic);
+        // every numerator 0 or of moderate magnitude, every denominator of moderate magnitude
+        ok = mag_ok(hl) && mag_nz(vl) && mag_nz(tv) && mag_nz(z) && rr > 1e-60 && rr < 1e60 && mag_nz(c_harmonic) &&
+             mag_ok(cos_t);
+    } else {
+        const T c_harmonic = z / (t.PS[il - 1] + hl / vl);
+        const T cos_t = z / sqrt(rr);
+        p0 = cos_t / c_harmonic;
+        ok = true;
+    }
     const T vmax = t.VMAX[il];
     const T vm1sq = (vmax + T(1.0)) * (vmax + T(1.0));
     // sum(sqrt(1-(p0**2)*(vp+1)**2)) is NaN  <=>  (p0*p0)*(vmax+1)^2 > 1  (monotone in V; the
@@ -513,6 +528,21 @@ __device__ __forceinline__ T initial_p0(const LayerTable<T> &t, int il, T R, T z
             return T(__builtin_nan(""));
     }
     return p0;
+}
+
+// `valid`: the lane carries a source (other lanes never veto the fast forms).  Every lane of the wave calls it.
+template <typename T>
+__device__ __forceinline__ T initial_p0(const LayerTable<T> &t, int il, T R, T z, bool valid = true)
+{
+    bool ok;
+    if constexpr (std::is_same<T, double>::value) {
+        T p0 = initial_p0_impl<true>(t, il, R, z, ok);
+        if (__any(valid && !ok))
+            p0 = initial_p0_impl<false>(t, il, R, z, ok);
+        return p0;
+    } else {
+        return initial_p0_impl<false>(t, il, R, z, ok);
+    }
 }
 
 template <typename T>

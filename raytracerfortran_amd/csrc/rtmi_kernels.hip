@@ -197,14 +197,29 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     a.d_depths += (int64_t)m * a.ld_model;
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
-    const LayerTable<T> t = carve_table(lds, a.nlayers);
-    stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
-    T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
-
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index: scalar
     const int nwib = blockDim.x >> 6;
     const int slots = a.slots;
+    // Source data of chunk c of the round that starts at j0 (0 outside the round / the source set).  The loads of
+    // a wave's next chunk are always requested before the current one is used, the very first ones before the
+    // layer table is built.
+    const int64_t nchunks_all = (a.nsrc + 63) / 64;
+    auto depth_of = [&](int64_t j0, int c) {
+        const int64_t chunk = (int64_t)blockIdx.x + (j0 + c) * (int64_t)gridDim.x;
+        const int64_t k = chunk * 64 + lane;
+        return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_depth[k] : T(0.0);
+    };
+    auto offset_of = [&](int64_t j0, int c) {
+        const int64_t chunk = (int64_t)blockIdx.x + (j0 + c) * (int64_t)gridDim.x;
+        const int64_t k = chunk * 64 + lane;
+        return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
+    };
+    T z_next = depth_of(0, wib);
+    const LayerTable<T> t = carve_table(lds, a.nlayers);
+    stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
+    T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
+
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
                                   ((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(a.nlayers) * sizeof(T) + 15) / 16 * 16);  // offset }
     T *rz = rR + slots;                                  // depth             } sorted by descending layer
@@ -251,13 +266,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             stamps[0] = clock64();
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t mycnt = 0;
-        // the next chunk's depths are requested before this chunk's are used (one global round trip in flight)
-        auto depth_of = [&](int c) {
-            const int64_t chunk = b + (j0 + c) * nblocks;
-            const int64_t k = chunk * 64 + lane;
-            return (c < CH && chunk < nchunks && k < a.nsrc) ? a.d_src_depth[k] : T(0.0);
-        };
-        T z_next = depth_of(wib);
+        if (j0 > 0)
+            z_next = depth_of(j0, wib);
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
             const T z = z_next;
-            z_next = depth_of(c + nwib);
+            z_next = depth_of(j0, c + nwib);
             int nl = which_layer(t, a.nlayers, z);
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
@@ -281,6 +291,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             }
         }
         hist[wib * 64 + lane] = mycnt;
+        T R_next = offset_of(j0, wib);  // in flight during the scan
+        z_next = depth_of(j0, wib);
         __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[4] = clock64();  // depths loaded, bins counted
@@ -316,13 +328,6 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         }
         __syncthreads();
         uint32_t woff = hist[wib * 64 + lane];  // lane b: next free slot of bin b for this wave
-        auto offset_of = [&](int c) {
-            const int64_t chunk = b + (j0 + c) * nblocks;
-            const int64_t k = chunk * 64 + lane;
-            return (c < CH && chunk < nchunks && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
-        };
-        T R_next = offset_of(wib);
-        z_next = depth_of(wib);
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
@@ -330,8 +335,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
             const T R = R_next, z = z_next;
-            R_next = offset_of(c + nwib);
-            z_next = depth_of(c + nwib);
+            R_next = offset_of(j0, c + nwib);
+            z_next = depth_of(j0, c + nwib);
             const int nl = valid ? (int)tnl[c * 64 + lane] : 1;
             const int bin = bin_of(nl, nl_max);
             uint32_t pos = 0;

@@ -272,7 +272,7 @@ def test_fast_math_equals_ieee(rt):
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 1 << 24
     total_s = total_d = total_t = 0
-    for trial in range(7):
+    for trial in range(8):
         u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         e = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if trial == 0:      # solver-like: w in (0, 1], numerators ~ H*V*p, denominators s and s^3
@@ -301,6 +301,10 @@ def test_fast_math_equals_ieee(rt):
             w = torch.exp(-27.0 * u)
             den = 1e5 + 1e7 * e
             num = den * 1e-4 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        elif trial == 7:    # initial_p0: sqrt(R^2 + z^2) and quotients of lengths and times, both sides of 1
+            w = torch.exp(276.0 * (u - 0.5))                  # 1e-60 .. 1e60
+            den = torch.exp(138.0 * (e - 0.5))                # 1e-30 .. 1e30
+            num = torch.where(u > 0.95, torch.zeros_like(u), torch.exp(138.0 * (u - 0.5)) * torch.sign(e - 0.2))
         else:               # the time pass: H / (V cos) with the whole guarded range of V cos, H = 0 included
             w = torch.exp(-138.0 * u)
             den = torch.exp(207.0 * (e - 2.0 / 3.0))          # 1e-60 .. 1e30
