@@ -283,7 +283,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const int bin = bin_of(nl, nl_max);
             unsigned long long todo = __ballot(nl > 1);
             while (todo) {
-                const int lb = __shfl(bin, __ffsll((long long)todo) - 1, 64);
+                const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
                 const unsigned long long grp = __ballot(nl > 1 && bin == lb);
                 if (lane == lb)
                     mycnt += (uint32_t)__popcll(grp);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 if (lane >= off)
                     incl += o;
             }
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t run = total - incl;  // first slot of bin `lane` when bins are laid out descending
             for (int w = 0; w < nwib; ++w) {
                 const uint32_t c = hist[w * 64 + lane];
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             uint32_t pos = 0;
             unsigned long long todo = __ballot(nl > 1);
             while (todo) {
-                const int lb = __shfl(bin, __ffsll((long long)todo) - 1, 64);
+                const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
                 const unsigned long long grp = __ballot(nl > 1 && bin == lb);
-                const uint32_t start = __shfl(woff, lb, 64);
+                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)woff, lb);
                 if (nl > 1 && bin == lb)
                     pos = start + (uint32_t)__popcll(grp & lt_mask);
                 if (lane == lb)
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                             tl = prev;
                         }
                     }
-                    base = __shfl(base, 0, 64);
+                    base = __builtin_amdgcn_readfirstlane(base);  // lane 0's value, as a scalar
                     if (base >= 0) {
                         if ((pm >> lane) & 1ull) {
                             const int i = base + __popcll(pm & lt_mask);
@@ -619,8 +619,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     }
                     base = head;
                 }
-                base = __shfl(base, 0, 64);
-                take = __shfl(take, 0, 64);
+                base = __builtin_amdgcn_readfirstlane(base);
+                take = __builtin_amdgcn_readfirstlane(take);
                 if (take > 0) {
                     const int r = __popcll(idle & lt_mask);
                     if (s.st == ST_DONE && r < take) {
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(&qctl[0], (uint32_t)nidle);
-                base = __shfl(base, 0, 64);
+                base = __builtin_amdgcn_readfirstlane(base);
                 exhausted = (int)base + nidle >= n_todo;
                 ++dg_refills;
                 if (DIAG && stamps && j0 == 0 && exhausted && lane == 0)
