@@ -198,14 +198,23 @@ __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T
     return c;
 }
 
+// Maximum over the wave of a NON-NEGATIVE value, as a scalar.  DPP row shifts and row broadcasts (no LDS
+// traffic): lanes without a source lane contribute 0.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
+#define RTMI_DPP_MAX(ctrl, row_mask)                                                  \
+    {                                                                                 \
+        const int o = __builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, 0xf, false);  \
+        v = o > v ? o : v;                                                            \
     }
-    return __builtin_amdgcn_readfirstlane(v);  // the same in every lane: let loops over it be scalar loops
+    RTMI_DPP_MAX(0x111, 0xf)  // row_shr:1
+    RTMI_DPP_MAX(0x112, 0xf)  // row_shr:2
+    RTMI_DPP_MAX(0x114, 0xf)  // row_shr:4
+    RTMI_DPP_MAX(0x118, 0xf)  // row_shr:8   -> lane 15 of every row holds the row's maximum
+    RTMI_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    RTMI_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef RTMI_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // whichLayer (:9-32): 1-based index of the first interface strictly below z; nlayers+1 below the
