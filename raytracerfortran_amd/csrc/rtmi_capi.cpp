@@ -75,7 +75,6 @@ struct Tuning {
     int refill_min;      // idle lanes that trigger a refill
     int tail_group;      // end-game concentration (records per wave group), 0 = off
     int retire_max;      // drain: live lanes a retiring wave hands over (0 = off)
-    int express_stop;    // express waves leave the last records of a round to the local waves (0 = off)
     int promote_age;     // trips after which a local wave hands a source to the express waves (0 = off)
     unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
     int diag_fine = 1;                       // ... including the per-trip clocks and counters
@@ -84,7 +83,7 @@ struct Tuning {
 Tuning &tuning()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, 256, 8, 0, 10, nullptr};
+        Tuning v{0, 4, 16, 256, 8, 10, nullptr};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -350,10 +349,6 @@ int rtmi_set_option(const char *name, int value)
         if (value < 1 || value > 64)
             return fail(RTMI_ERR_BAD_ARG, "refill_min must be in [1, 64]");
         t.refill_min = value;
-    } else if (!strcmp(name, "express_stop")) {
-        if (value < 0 || value > 4096)
-            return fail(RTMI_ERR_BAD_ARG, "express_stop must be in [0, 4096]");
-        t.express_stop = value;
     } else if (!strcmp(name, "diag_fine")) {
         t.diag_fine = value != 0;
     } else if (!strcmp(name, "promote_age")) {
@@ -413,7 +408,6 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
         fa.promote_age = tn.promote_age;
-        fa.express_stop = tn.express_stop;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -536,7 +530,6 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
         fa.promote_age = tn.promote_age;
-        fa.express_stop = tn.express_stop;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
         fa.nsrc = c.set_n;
@@ -591,7 +584,6 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
         fa.promote_age = tn.promote_age;
-        fa.express_stop = tn.express_stop;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;
@@ -676,7 +668,6 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
         fa.promote_age = tn.promote_age;
-        fa.express_stop = tn.express_stop;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
         fa.nsrc = nsrc;

@@ -46,7 +46,6 @@ struct FusedArgsT {
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
-    int express_stop;            // express waves take no fresh records once fewer than this remain queued (0 = off)
     int promote_age;             // local waves hand a source to the express waves after this many trips (0 = off)
     int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off)
     const T *d_src_offset;  // [nsrc]

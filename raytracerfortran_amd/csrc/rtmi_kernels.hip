@@ -415,6 +415,28 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
                 rk[q] = k2;
             }
+            // per-chunk class counts and the lane's rank within its class: what the solve order is built from
+            {
+                const bool todo = valid && s.st != ST_DONE;
+                const int cls = (int)((rk[q < nq ? q : 0] >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
+                unsigned long long w0 = 0, w1 = 0, mine = 0;
+#pragma unroll
+                for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
+                    const unsigned long long bk = __ballot(todo && cls == k);
+                    if (cls == k)
+                        mine = bk;
+                    if (k < 4)
+                        w0 |= (unsigned long long)__popcll(bk) << (16 * k);
+                    else
+                        w1 |= (unsigned long long)__popcll(bk) << (16 * (k - 4));
+                }
+                if (lane == 0) {
+                    ch_cnt[q0 >> 6] = w0;
+                    ch_cnt[128 + (q0 >> 6)] = w1;
+                }
+                if (valid)
+                    tnl[q] = todo ? ((uint32_t)cls | ((uint32_t)__popcll(mine & lt_mask) << 3)) : 0xFFFFFFFFu;
+            }
         }
         __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
@@ -424,24 +446,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         // order[] = class 0, class 1, ... (most expected evaluations first; the short class last), each in slot
         // order (= descending layer index), built from per-chunk ballots (deterministic).  Longest first is
         // what keeps the end of the round short: the last records handed out are the cheapest ones.
-        const int nchq = (nq + 63) >> 6;  // <= 127
-        for (int c = wib; c < nchq; c += nwib) {
-            const int q = c * 64 + lane;
-            const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
-            const bool todo = !(key & RTMI_RK_DONE);
-            const int cls = (int)((key >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
-            unsigned long long w0 = 0, w1 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                w0 |= (unsigned long long)__popcll(__ballot(todo && cls == k)) << (16 * k);
-                w1 |= (unsigned long long)__popcll(__ballot(todo && cls == k + 4)) << (16 * k);
-            }
-            if (lane == 0) {
-                ch_cnt[c] = w0;
-                ch_cnt[128 + c] = w1;
-            }
-        }
-        __syncthreads();
+        const int nchq = (nq + 63) >> 6;  // <= 127; the counts were taken in a2
         if (wib == 0) {
             // lane l owns chunks 2l and 2l+1: exclusive prefix of the counts (16-bit fields, no carry: <= 8128)
             const int c0 = 2 * lane, c1 = 2 * lane + 1;
@@ -477,19 +482,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         const int n_todo = __builtin_amdgcn_readfirstlane((int)cls_base[RTMI_RK_CLASSES]);
         for (int c = wib; c < nchq; c += nwib) {
             const int q = c * 64 + lane;
-            const uint32_t key = q < nq ? rk[q] : RTMI_RK_DONE;
-            const bool todo = !(key & RTMI_RK_DONE);
-            const int cls = (int)((key >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
-            unsigned long long mine = 0;
-#pragma unroll
-            for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
-                const unsigned long long bk = __ballot(todo && cls == k);
-                if (cls == k)
-                    mine = bk;
-            }
-            if (todo) {
+            const uint32_t v = q < nq ? tnl[q] : 0xFFFFFFFFu;  // class | rank within (chunk, class) << 3
+            if (v != 0xFFFFFFFFu) {
+                const int cls = (int)(v & 7u);
                 const uint32_t st = (uint32_t)((ch_start[128 * (cls >> 2) + c] >> (16 * (cls & 3))) & 0xFFFFull);
-                order[cls_base[cls] + st + (uint32_t)__popcll(mine & lt_mask)] = (uint16_t)q;
+                order[cls_base[cls] + st + (v >> 3)] = (uint16_t)q;
             }
         }
         __syncthreads();
@@ -524,12 +521,9 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         const bool split = nwib > 4 && n_todo >= (int)blockDim.x && (a.retire_max > 0 || promote_age > 0);
         const bool local = split && wib >= 4;
         const bool express = split && wib < 4;
-        // this wave stops taking fresh records once fewer than stop_below remain queued: with express_stop the
-        // express waves leave the last (short) records to the local waves and keep to the long sources handed to
-        // them; the local wave groups (or, without express_stop, all groups) stop one after the other
-        const int express_stop = split ? (a.express_stop < n_todo / 3 ? a.express_stop : n_todo / 3) : 0;
-        const int stop_below = express_stop > 0 ? (wib < 4 ? express_stop : ((wib >> 2) - 1) * tail_group)
-                                                : (wib >> 2) * tail_group;
+        // End-game concentration: the last records of the queue go to the first waves only (wave group g =
+        // wib / 4 stops refilling once fewer than g * tail_group records remain).
+        const int stop_below = (wib >> 2) * tail_group;
         bool left = false;  // (local) this wave has signed off from rg[3]
         int spins = 0;
         int nfull_wave = 0;
@@ -663,8 +657,6 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 dg_t0 = dg_t1;
             }
             // -- fresh records from the queue -----------------------------------------------------------------
-            // End-game concentration: the last records of the queue go to the first waves only (wave group g =
-            // wib / 4 stops refilling once fewer than g * tail_group records remain).
             if (!exhausted && nidle >= a.refill_min && stop_below > 0 &&
                 n_todo - __builtin_amdgcn_readfirstlane((int)qctl[0]) < stop_below) {
                 exhausted = true;
