@@ -554,6 +554,20 @@ __device__ __forceinline__ T initial_p0(const LayerTable<T> &t, int il, T R, T z
     }
 }
 
+// Source in the top layer (:94-97): t = sqrt(z^2 + R^2) / v_1.  Called from divergent code (the lanes of a chunk
+// that are straight rays): the guarded forms when every such lane is inside the guards, the plain operators otherwise.
+template <typename T>
+__device__ __forceinline__ T straight_time(T z, T R, T v0)
+{
+    const T rr = z * z + R * R;
+    if constexpr (std::is_same<T, double>::value) {
+        const bool ok = rr > 1e-60 && rr < 1e60 && mag_nz(v0);
+        if (__all(ok))
+            return div_guarded(sqrt_guarded(rr), v0);
+    }
+    return sqrt(rr) / v0;
+}
+
 template <typename T>
 __device__ __forceinline__ void lane_start(Lane<T> &s, T p0)
 {

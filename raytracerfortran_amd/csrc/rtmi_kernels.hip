@@ -279,16 +279,20 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             int nl = which_layer(t, a.nlayers, z);
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
-            tnl[c * 64 + lane] = (uint32_t)nl;
             const int bin = bin_of(nl, nl_max);
+            uint32_t rank = 0;  // of this record among the wave's records of its bin (chunks in order, lanes in order)
             unsigned long long todo = __ballot(nl > 1);
             while (todo) {
                 const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
                 const unsigned long long grp = __ballot(nl > 1 && bin == lb);
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, lb);
+                if (nl > 1 && bin == lb)
+                    rank = before + (uint32_t)__popcll(grp & lt_mask);
                 if (lane == lb)
                     mycnt += (uint32_t)__popcll(grp);
                 todo &= ~grp;
             }
+            tnl[c * 64 + lane] = (uint32_t)nl | (rank << 11);  // nl <= 1025, rank < 8192
         }
         hist[wib * 64 + lane] = mycnt;
         T R_next = offset_of(j0, wib);  // in flight during the scan
@@ -327,7 +331,6 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 pl_ready[i] = 0;
         }
         __syncthreads();
-        uint32_t woff = hist[wib * 64 + lane];  // lane b: next free slot of bin b for this wave
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
@@ -337,24 +340,14 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const T R = R_next, z = z_next;
             R_next = offset_of(j0, c + nwib);
             z_next = depth_of(j0, c + nwib);
-            const int nl = valid ? (int)tnl[c * 64 + lane] : 1;
-            const int bin = bin_of(nl, nl_max);
-            uint32_t pos = 0;
-            unsigned long long todo = __ballot(nl > 1);
-            while (todo) {
-                const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
-                const unsigned long long grp = __ballot(nl > 1 && bin == lb);
-                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)woff, lb);
-                if (nl > 1 && bin == lb)
-                    pos = start + (uint32_t)__popcll(grp & lt_mask);
-                if (lane == lb)
-                    woff += (uint32_t)__popcll(grp);
-                todo &= ~grp;
-            }
+            const uint32_t packed = valid ? tnl[c * 64 + lane] : 1u;
+            const int nl = (int)(packed & 0x7FFu);
+            // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
+            const uint32_t pos = hist[wib * 64 + bin_of(nl, nl_max)] + (packed >> 11);
             if (valid) {
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
-                    const T tt = sqrt(z * z + R * R) / t.V[0];
+                    const T tt = straight_time(z, R, t.V[0]);
                     if (WANT_T)
                         a.d_timeP[k] = tt;
                     if (WANT_P)
