@@ -476,6 +476,8 @@ struct Lane {
     T hvl;   // (z - D[il-1]) * V[il]   partial layer of the source
     T vvl;   // V[il]^2
     T vmi;   // 1/maxval(vp)
+    T safe;  // 1/maxval(vp) - 1d-10   (:142, :388)   } per-source constants of the state machine, kept in
+    T clampv;  // 1/maxval(vp) - 1d-9  (:299-304)     } registers instead of being recomputed every trip
     T x;     // Newton iterate / final ray parameter
     T xe;    // where the next (f, f') evaluation happens
     T xb;    // bisection bracket end `x` of solvebst
@@ -497,6 +499,8 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
     s.hvl = hl * vl;
     s.vvl = t.VV[il];
     s.vmi = t.VMI[il];
+    s.safe = s.vmi - T(1e-10);
+    s.clampv = s.vmi - T(1e-9);
     s.nfull = il;
     s.numer_ok = mag_ok(s.hvl) && (t.HVOK[il - 1] != T(0.0));
 }
@@ -595,13 +599,15 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
     const bool isI = MODE == ADV_INIT_ONLY ? true : (MODE == ADV_NO_INIT ? false : st == ST_INIT);
-    const bool isB0 = MODE != ADV_INIT_ONLY && (st == ST_BIS0), isB = MODE != ADV_INIT_ONLY && (st == ST_BIS),
+    // ST_BIS0 comes up once per bisection source: in the fused kernel's solve loop (ADV_NO_INIT) it is handled by a
+    // block of its own, entered only on trips where some lane is in that state, and is no operand of the selects.
+    const bool isB0 = MODE == ADV_ANY && (st == ST_BIS0), isB = MODE != ADV_INIT_ONLY && (st == ST_BIS),
                isN = MODE != ADV_INIT_ONLY && (st == ST_NEWTON), isF = MODE != ADV_INIT_ONLY && (st == ST_FINAL);
     // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294): same operands, one divide
     const T q = f / fp;
     const bool neg = f < T(0.0);
     const bool small = fabs(f) < T(0.1);   // abs(fx) < tol (:287), abs(fmid) < tol (:394)
-    const T safe = s.vmi - T(1e-10);  // 1/maxval(V)-(1d-10)      (:142, :388)
+    const T safe = s.safe;  // 1/maxval(V)-(1d-10)      (:142, :388)
 
     // solvebst trip, first half: `if (fmid < 0) x = xmid` (:371-373)
     const T xb1 = (isB && neg) ? s.xe : s.xb;
@@ -625,7 +631,7 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     const bool n_go = newt && !small;
     T xnew = xN - q;                // x = x - deltax (:298)
     if (xnew > s.vmi)
-        xnew = s.vmi - T(1e-9);             // (:299-304)
+        xnew = s.clampv;                    // (:299-304)
 
     // solvebst entry (:354-365): x1 = 1d-10, x2 = 1/maxval(vp)-1d-12
     const T x2 = s.vmi - T(1e-12);
@@ -650,6 +656,23 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
                                       : bis_done ? ST_NEWTON
                                                  : n_go ? (kN == 15 ? ST_FINAL : ST_NEWTON)
                                                         : (n_conv || isF) ? ST_DONE : st;
+    if constexpr (MODE == ADV_NO_INIT) {
+        const bool b0 = (st == ST_BIS0);  // untouched by everything above
+        if (__any(b0)) {
+            // solvebst entry (:354-365), then dx = dx*0.5; xmid = x + dx (:368-369)
+            const T e2 = s.vmi - T(1e-12);
+            const T e21 = e2 - T(1e-10);
+            const T b_x = neg ? T(1e-10) : e2;
+            const T b_dx = (neg ? e21 : -e21) * T(0.5);
+            if (b0) {
+                s.xb = b_x;
+                s.dx = b_dx;
+                s.xe = b_x + b_dx;
+                s.k = 1;
+                s.st = ST_BIS;
+            }
+        }
+    }
 }
 
 // Travel time for a known ray parameter (:156, :165-166): tt = sum H_i / (V_i * sqrt(1 - p^2 V_i^2)) over the

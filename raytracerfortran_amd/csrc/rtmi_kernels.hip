@@ -500,7 +500,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         Lane<T> s;
         s.st = ST_DONE;
         s.nfull = 0;
-        s.R = s.hvl = s.vvl = s.vmi = s.x = s.xe = s.xb = s.dx = T(0.0);
+        s.R = s.hvl = s.vvl = s.vmi = s.safe = s.clampv = s.x = s.xe = s.xb = s.dx = T(0.0);
         s.k = 0;
         s.conv = false;
         s.numer_ok = true;
