@@ -178,9 +178,11 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
     __syncthreads();
 }
 
-// Class 0..6 of a source that starts with the bisection, by the evaluations it is expected to take (about
-// 5.5 + 2 log2((R - A) / H_j), see stage_model): 0 = more than ~21, then steps of about two down to 6 = at most
-// ~10.  A scheduling hint: it decides when the source is handed to a lane, nothing else.
+// Class of a source that starts with the bisection, by the evaluations it is expected to take (about
+// 5.5 + 2 log2((R - A) / H_j), see stage_model): RTMI_TRIP_CLASSES - 1 for the cheapest, one less per threshold
+// passed.  Three classes are in use (measured: finer classes finish the lanes of a wave closer together but mix
+// the layer counts inside a wave more; seven classes were 2 % slower, two 1 % slower).  A scheduling hint: it
+// decides when the source is handed to a lane, nothing else.
 template <typename T>
 __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T z)
 {
@@ -189,12 +191,8 @@ __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T
     const T hj = t.PH[il];
     const T den = hj > T(0.0) ? hj : hl;
     int c = RTMI_TRIP_CLASSES - 1;
-    c -= (num > den * T(4.76));    // 2^2.25
-    c -= (num > den * T(9.51));    // 2^3.25
-    c -= (num > den * T(19.0));    // 2^4.25
-    c -= (num > den * T(38.1));    // 2^5.25
-    c -= (num > den * T(90.5));    // 2^6.5
-    c -= (num > den * T(256.0));   // 2^8
+    c -= (num > den * T(9.51));    // 2^3.25: about 12 evaluations or more
+    c -= (num > den * T(64.0));    // 2^6:    about 17.5 or more
     return c;
 }
 
