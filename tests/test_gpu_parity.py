@@ -537,3 +537,48 @@ def test_many_layers(rt, O):
         assert compare_times(t, O.oracle_dff(v, d, off, dep), TOL) == 0.0
     with pytest.raises(rt.RtmiError):
         rt.dff(np.ones(1026) * 3000, np.arange(1, 1026.0), 1025, [1.0], [1.0], 1)
+
+
+def test_fused_kernel_random_model_soak(rt, O):
+    """Random models of every shape the sampler's prior can draw and a few it cannot (monotone, low-velocity zones,
+    tied maxima, thin and thick layers, 1..60 interfaces, velocities over three decades), source sets from 9 000 to
+    150 000, shallow and deep, near and far: the fused kernel -- whose solve order comes from a per-model estimate
+    of the evaluation count -- returns the oracle's bits for every source, final ray parameters included."""
+    import torch
+    rng = np.random.default_rng(987654321)
+    nsrc_total = 0
+    for it in range(48):
+        k = int(rng.integers(2, 62))
+        kind = it % 6
+        if kind == 0:      # monotone increasing
+            v = np.sort(rng.uniform(1500, 8000, k))
+        elif kind == 1:    # prior draw
+            v = rng.uniform(1500, 10000, k)
+        elif kind == 2:    # tied maxima and a low-velocity zone
+            v = rng.uniform(2000, 6000, k)
+            v[rng.integers(0, k, 3)] = 6000.0
+        elif kind == 3:    # slow sediments over a fast basement
+            v = np.concatenate([rng.uniform(300, 900, k - 1), [7000.0]])
+        elif kind == 4:    # velocities over three decades
+            v = np.exp(rng.uniform(np.log(50.0), np.log(50000.0), k))
+        else:              # decreasing with depth
+            v = np.sort(rng.uniform(1500, 8000, k))[::-1].copy()
+        thick = rng.uniform(1.0, 900.0, k - 1) if it % 2 else np.exp(rng.uniform(np.log(0.5), np.log(3000.0), k - 1))
+        d = np.cumsum(thick)
+        n = int(rng.integers(9000, 150000))
+        off = np.where(rng.random(n) < 0.5, rng.uniform(0.0, 3.0 * d[-1] + 100.0, n), np.exp(rng.uniform(-3, 11, n)))
+        dep = np.where(rng.random(n) < 0.7, rng.uniform(0.01, d[-1] * 1.2 + 10.0, n), rng.choice(d, n) + rng.choice([0.0, 1e-9, -1e-9, 0.5], n))
+        dep = np.abs(dep) + 1e-6
+        p = torch.empty(n, dtype=torch.float64, device="cuda")
+        try:
+            rt.set_option("path", 2)
+            t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
+                                torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda"), p_final=p).cpu().numpy()
+        finally:
+            rt.set_option("path", 0)
+        ref, pref, nl = O.oracle_dff(v, d, off, dep, want_p=True)
+        assert np.array_equal(t, ref, equal_nan=True), (it, kind, k, n, int((t != ref).sum()))
+        good = nl > 1
+        assert np.array_equal(p.cpu().numpy()[good], pref[good], equal_nan=True), (it, kind, k, n)
+        nsrc_total += n
+    assert nsrc_total > 2_000_000
