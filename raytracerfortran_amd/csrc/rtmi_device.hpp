@@ -30,6 +30,12 @@ enum : int {
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
 #endif
 #define RTMI_TABLE_STRIDE(nlayers) ((nlayers) + 2)
+// Models of up to RTMI_ROWS_MAX_NL interfaces also get the pair table once per stack height ("rows", see LayerTable);
+// `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
+#define RTMI_ROWS_MAX_NL 20
+#define RTMI_TABLE_ELEMS(nlayers, rows) \
+    (((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(nlayers) + 1) / 2 * 2 + \
+     ((rows) ? (size_t)2 * ((nlayers) + 1) * ((nlayers) + 1) : 0))
 template <typename T>
 struct alignas(2 * sizeof(T)) LayerPair {
     T hv, vv;
@@ -39,6 +45,10 @@ struct LayerTable {
     LayerPair<T> *HW;  // HW[i] = {HV[i], VV[i]} i < nlayers: what one layer term reads; HW[nul] = {0, 0} is the
                        // "no layer" entry: its term is exactly 0 for every finite x
     int nul;           // = nlayers + 1
+    LayerPair<T> *HWR; // rows (or nullptr): HWR[r * row_len + i] = HW[i] for i < r, {0, 0} for r <= i < row_len, one
+                       // row per number r of fully crossed layers.  A lane reads its own row at a wave-uniform
+                       // column, so the layer loop needs no per-lane index arithmetic at all.
+    int row_len;       // = nlayers + 1
     T *D;     // D[i]    depth to interface i                       i < nlayers
     T *V;     // V[i]    velocity of layer i                        i <= nlayers
     T *H;     // H[i]    thickness of a fully crossed layer i       i < nlayers
@@ -56,7 +66,7 @@ struct LayerTable {
 };
 
 template <typename T>
-__device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers)
+__device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool rows = false)
 {
     const int n1 = RTMI_TABLE_STRIDE(nlayers);
     LayerTable<T> t;
@@ -75,6 +85,8 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers)
     t.PA = lds + 12 * n1;
     t.PC = lds + 13 * n1;
     t.PH = lds + 14 * n1;
+    t.HWR = rows ? reinterpret_cast<LayerPair<T> *>(lds + ((size_t)RTMI_TABLE_ARRAYS * n1 + 1) / 2 * 2) : nullptr;
+    t.row_len = nlayers + 1;
     return t;
 }
 
@@ -146,6 +158,16 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         }
     }
     __syncthreads();
+    if (t.HWR) {
+        const int n = t.row_len * t.row_len;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int r = e / t.row_len, i = e - r * t.row_len;
+            LayerPair<T> v;
+            v.hv = i < r ? t.HW[i].hv : T(0.0);
+            v.vv = i < r ? t.HW[i].vv : T(0.0);
+            t.HWR[e] = v;
+        }
+    }
     for (int i = threadIdx.x; i <= nlayers; i += blockDim.x)
         t.VMI[i] = T(1.0) / t.VMAX[i];
     if constexpr (WITH_HINT) {
@@ -411,10 +433,14 @@ __device__ __forceinline__ bool add_terms(T xx, T x, const T (&hv)[N], const T (
 // `nfull_wave` >= max of nfull over the wave keeps the loop wave-uniform.
 // Terms are evaluated two at a time (two independent sqrt/divide chains in flight: the evaluation is a long
 // dependent chain, and in the drain a wave has its SIMD to itself) and ADDED strictly in layer order.
-template <bool FAST, typename T>
+template <bool FAST, bool ROWS, typename T>
 __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
                                            T vvl, T R, T &f, T &fp)
 {
+    // ROWS: the lane reads row `nfull` of the row table at the wave-uniform column i (zeros past its stack);
+    // otherwise it picks entry i or the "no layer" entry of the one shared table.
+    const LayerPair<T> *row = ROWS ? t.HWR + nfull * t.row_len : t.HW;
+    auto entry = [&](int i) -> LayerPair<T> { return ROWS ? row[i] : t.HW[i < nfull ? i : t.nul]; };
     // No lane is masked inside the loop: a lane whose stack ends before layer i reads the table's "no layer"
     // entry {0, 0} instead, whose term is (0*x)/sqrt(1) = 0 and 0/1 = 0, and sf + 0 == sf bit for bit (sf is never
     // -0: it starts at +0).  That keeps the loop free of EXEC masks and branches, so the two chains of a pair are
@@ -427,20 +453,20 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
         T hv[RTMI_TERM_GROUP], vv[RTMI_TERM_GROUP];
 #pragma unroll
         for (int j = 0; j < RTMI_TERM_GROUP; ++j) {
-            const LayerPair<T> e = t.HW[i + j < nfull ? i + j : t.nul];
+            const LayerPair<T> e = entry(i + j);
             hv[j] = e.hv;
             vv[j] = e.vv;
         }
         ok = add_terms<FAST, RTMI_TERM_GROUP>(xx, x, hv, vv, sf, sp) && ok;
     }
     for (; i + 1 < nfull_wave; i += 2) {
-        const LayerPair<T> e0 = t.HW[i < nfull ? i : t.nul];
-        const LayerPair<T> e1 = t.HW[i + 1 < nfull ? i + 1 : t.nul];
+        const LayerPair<T> e0 = entry(i);
+        const LayerPair<T> e1 = entry(i + 1);
         const T hv[2] = {e0.hv, e1.hv}, vv[2] = {e0.vv, e1.vv};
         ok = add_terms<FAST, 2>(xx, x, hv, vv, sf, sp) && ok;
     }
     if (i < nfull_wave) {  // wave-uniform: the odd full layer together with the source's own partial layer
-        const LayerPair<T> e0 = t.HW[i < nfull ? i : t.nul];
+        const LayerPair<T> e0 = entry(i);
         const T hv[2] = {e0.hv, hvl}, vv[2] = {e0.vv, vvl};
         ok = add_terms<FAST, 2>(xx, x, hv, vv, sf, sp) && ok;
     } else {
@@ -454,16 +480,16 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
 
 // `numer_ok`: lane-constant part of the guard (table products and hvl are 0 or of moderate magnitude).
 // `busy`: the lane carries a live source (idle lanes never veto the fast path).
-template <typename T>
+template <bool ROWS = false, typename T>
 __device__ __forceinline__ void eval_f_fp(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
                                           T vvl, T R, bool numer_ok, bool busy, T &f, T &fp)
 {
     if constexpr (std::is_same<T, double>::value) {
-        const bool ok = eval_terms<true>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
+        const bool ok = eval_terms<true, ROWS>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
         if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
-            eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
+            eval_terms<false, false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
     } else {
-        eval_terms<false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);  // fp32: plain IEEE sqrtf and divide
+        eval_terms<false, ROWS>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);  // fp32: plain IEEE sqrtf and divide
     }
 }
 

@@ -216,12 +216,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
     T z_next = depth_of(0, wib);
-    const LayerTable<T> t = carve_table(lds, a.nlayers);
+    const LayerTable<T> t = carve_table(lds, a.nlayers, a.rows != 0);
     stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
-                                  ((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(a.nlayers) * sizeof(T) + 15) / 16 * 16);  // offset }
+                                  (RTMI_TABLE_ELEMS(a.nlayers, a.rows != 0) * sizeof(T) + 15) / 16 * 16);  // offset }
     T *rz = rR + slots;                                  // depth             } sorted by descending layer
     T *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
@@ -389,7 +389,10 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
             T f, fp;
-            eval_f_fp(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            if (a.rows)
+                eval_f_fp<true>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            else
+                eval_f_fp<false>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
             if (live)
                 lane_advance<ADV_INIT_ONLY>(s, f, fp);
             if (valid) {
@@ -738,7 +741,10 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 dg_terms += (unsigned long long)terms;
                 dg_t0 = clock64();
             }
-            eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
+            if (a.rows)
+                eval_f_fp<true>(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
+            else
+                eval_f_fp<false>(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
             if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
@@ -859,7 +865,7 @@ static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &a, int nmodels, int 
                                  hipStream_t stream)
 {
     using namespace rtmi;
-    const size_t lds_bytes = (size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(max_nlayers) * sizeof(T);
+    const size_t lds_bytes = RTMI_TABLE_ELEMS(max_nlayers, false) * sizeof(T);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
@@ -923,7 +929,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = ((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(max_nlayers) * elem_bytes + 15) / 16 * 16;
+    const size_t table = (RTMI_TABLE_ELEMS(max_nlayers, max_nlayers <= RTMI_ROWS_MAX_NL) * elem_bytes + 15) / 16 * 16;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
                          (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
                          (128 + 128) * sizeof(uint32_t);
@@ -992,6 +998,7 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
             return e;
     }
     FusedArgsT<T> a = args;
+    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;  // launch-wide: the layer tables carry one row per stack height
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
