@@ -18,7 +18,7 @@ Output: ONE JSON line on rank 0 (contract in the task statement) with
                 (8 B offset + 8 B depth read, 8 B timeP written) / average kernel duration
                 measured with HIP events on the launch stream, against 8 TB/s.  The kernel is
                 fp64-VALU bound (DESIGN.md), so this fraction is small by construction;
-                `valu_fp64` next to it prices the same launch in executed fp64 flops.
+                `valu_fp64` next to it prices the same launch against the fp64 VALU issue rate.
   cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on the
                 same workload -- baseline only.
 """
@@ -79,9 +79,10 @@ def host_cores() -> int:
     return min(n, int(os.environ.get("RTMI_BENCH_MAX_THREADS", "64")))
 
 
-def measured_traffic(kernel_substr: str = "fused_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/<tag>/pmc_summary.json, newest tag; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+def measured_counters(kernel_substr: str = "fused_kernel"):
+    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
+    (profiles/<tag>/pmc_summary.json, newest tag): (HBM bytes with FETCH_SIZE doubled per the gfx950 correction,
+    VALU wave-instructions, source file).  None if absent."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json"))):
@@ -91,8 +92,14 @@ def measured_traffic(kernel_substr: str = "fused_kernel"):
             continue
         for k, c in d.items():
             if kernel_substr in k and "hbm_bytes_per_launch" in c:
-                best = (c["hbm_bytes_per_launch"]["total"], os.path.relpath(path, ROOT))
+                valu = c.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
+                best = (c["hbm_bytes_per_launch"]["total"], valu, os.path.relpath(path, ROOT))
     return best
+
+
+def measured_traffic(kernel_substr: str = "fused_kernel"):
+    m = measured_counters(kernel_substr)
+    return None if m is None else (m[0], m[2])
 
 
 def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
@@ -328,13 +335,21 @@ def main():
         if tr is not None and n == 1_000_000:
             res["roofline"]["traffic"] = tr[0]
             res["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-        # the roof that actually binds: fp64 vector ALU.  Executed wave-instructions come from the same PMC passes
-        # (SQ_INSTS_VALU); ~1.4 flop per fp64 instruction (fma = 2, the rest 1).
-        res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                            "useful_fp64_instr_per_travel_time": 2600,
-                            "useful_instr_rate_T_per_s": 2600 * value / 1e12,
-                            "note": "useful = oracle-counted evaluations x layers x (1 sqrt + 2 div + 9 flops); "
-                                    "DESIGN.md section 4.2"}
+        # the roof that actually binds: the fp64 vector ALU.  One wave-instruction occupies a SIMD for 4 cycles
+        # (v_rsq/v_rcp_f64: 16), i.e. 16 lanes per clock and SIMD = FP64_VALU_PEAK_TFLOPS / 2 lane-instructions per
+        # second over the chip.  Executed instructions come from the same PMC passes (SQ_INSTS_VALU); the useful part
+        # is the layer terms the reference's arithmetic needs: 41.7 per travel time on this workload (counted by the
+        # instrumented kernel, profiles/r01m/phase_clocks.txt) x 33 instructions each.
+        peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
+        res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
+                            "useful_term_instr_per_travel_time": 41.7 * 33,
+                            "useful_frac_of_peak": 41.7 * 33 * value / peak_lane_instr,
+                            "note": "fp64 VALU issue is the binding roof (DESIGN.md section 4.2)"}
+        mc = measured_counters()
+        if mc is not None and mc[1] and n == 1_000_000 and kern_ms:
+            res["valu_fp64"]["executed_valu_wave_instr_per_launch"] = mc[1]
+            res["valu_fp64"]["executed_frac_of_peak"] = mc[1] * 64.0 / (kern_ms * 1e-3) / peak_lane_instr
+            res["valu_fp64"]["source"] = mc[2]
         if check is not None:
             res["check_vs_oracle"] = check
         if world == 1 and not args.no_cpu_baseline:
