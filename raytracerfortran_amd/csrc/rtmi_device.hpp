@@ -699,6 +699,58 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     }
 }
 
+// lane_advance for the fused kernel's solve loop (states BIS0, BIS, NEWTON, FINAL; never INIT), one block per state,
+// each skipped when no lane of the wave is in that state.  With the longest-first solve order the lanes of a wave
+// are mostly in the same phase of their solves, so most trips execute one block; inside a block the updates are
+// plain masked writes instead of chains of selects.  Same operations on the same operands as lane_advance.
+template <typename T>
+__device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
+{
+    const int st = s.st;
+    const T q = f / fp;                      // deltax of solvebst (:384) and of solve (:294)
+    const bool neg = f < T(0.0);
+    const bool small = fabs(f) < T(0.1);     // abs(fx) < tol (:287), abs(fmid) < tol (:394)
+    if (st == ST_BIS) {
+        const T xb1 = neg ? s.xe : s.xb;     // `if (fmid < 0) x = xmid` (:371-373)
+        const T check_x = xb1 - q;           // (:386)
+        const bool jump = check_x < s.safe;
+        const bool zero = (f == T(0.0));
+        const bool done = zero || jump || small || s.k == 20;  // (:375, :388, :394, maxiter)
+        const T xb2 = (!zero && jump) ? s.xe : xb1;            // (:388-391) x = xmid; exit
+        const T dxh = s.dx * T(0.5);         // dx = dx*0.5; xmid = x + dx (:368-369)
+        s.xb = xb2;
+        s.dx = done ? s.dx : dxh;
+        s.xe = done ? xb2 : xb2 + dxh;
+        s.x = done ? xb2 : s.x;
+        s.k = done ? 1 : s.k + 1;
+        s.st = done ? ST_NEWTON : ST_BIS;
+    } else if (st == ST_NEWTON) {
+        T xnew = s.x - q;                    // x = x - deltax (:298)
+        if (xnew > s.vmi)
+            xnew = s.clampv;                 // (:299-304)
+        const bool last = (s.k == 15);
+        s.conv = small ? true : s.conv;      // (:288)
+        s.x = small ? s.x : xnew;
+        s.xe = small ? s.xe : xnew;
+        s.k = (small || last) ? s.k : s.k + 1;
+        s.st = small ? ST_DONE : (last ? ST_FINAL : ST_NEWTON);
+    } else if (st == ST_FINAL) {
+        s.conv = fabs(f) > T(0.1);           // the inverted test (:327-330)
+        s.st = ST_DONE;
+    } else if (st == ST_BIS0) {
+        // solvebst entry (:354-365): x1 = 1d-10, x2 = 1/maxval(vp)-1d-12, then dx = dx*0.5; xmid = x + dx
+        const T e2 = s.vmi - T(1e-12);
+        const T e21 = e2 - T(1e-10);
+        const T b_x = neg ? T(1e-10) : e2;
+        const T b_dx = (neg ? e21 : -e21) * T(0.5);
+        s.xb = b_x;
+        s.dx = b_dx;
+        s.xe = b_x + b_dx;
+        s.k = 1;
+        s.st = ST_BIS;
+    }
+}
+
 // Travel time for a known ray parameter (:156, :165-166): tt = sum H_i / (V_i * sqrt(1 - p^2 V_i^2)) over the
 // fully crossed layers, then the partial layer.  Wave-uniform loop, two layers side by side, no lane masked: a
 // lane whose stack has ended reads the "no layer" entry (H = 0, V = 1, VV = 0), whose term is 0 / 1.

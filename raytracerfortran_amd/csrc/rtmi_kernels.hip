@@ -749,7 +749,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
             }
-            lane_advance<ADV_NO_INIT>(s, f, fp);
+            lane_advance_solve(s, f, fp);
             ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
