@@ -25,7 +25,7 @@ enum : int {
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of RTMI_TABLE_STRIDE(nlayers) elements; the pair
 // array HW comes first (16-byte aligned for the fp64 build) and takes two of them.
 #define RTMI_TABLE_ARRAYS 15
-#define RTMI_TRIP_CLASSES 7  // classes of trip_class (the fused kernel's solve order puts the Newton-only class after them)
+#define RTMI_TRIP_CLASSES 3  // classes of trip_class (the fused kernel's solve order puts the Newton-only class after them)
 #ifndef RTMI_TERM_GROUP
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
 #endif

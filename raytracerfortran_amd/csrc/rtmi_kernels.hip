@@ -176,8 +176,8 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..23 (nl <= 1025)
 #define RTMI_RK_NL_MASK 0x7FFu
-#define RTMI_RK_CLASS_SHIFT 24        // rk: class of the solve order in bits 24..26 (0 = most evaluations expected)
-#define RTMI_RK_CLASSES 8
+#define RTMI_RK_CLASS_SHIFT 24        // rk: class of the solve order in bits 24..25 (0 = most evaluations expected)
+#define RTMI_RK_CLASSES 4             // RTMI_TRIP_CLASSES classes of bisection sources + the Newton-only class
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
 #define RTMI_RK_DONE 0x40000000u      // rk: finished by its first evaluation (or p0 is NaN): not in the solve order
@@ -242,10 +242,10 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     volatile lds_int *pl_ctl = pl_ready + RTMI_POOL;            // [0] tail (reserved), [1] head (claimed), [2] local waves still solving
     // exact solve order: per 64-slot chunk, counts and first order[] positions of the two classes
     uint32_t *cls_base = reinterpret_cast<uint32_t *>(pl_state + 2 * RTMI_POOL + 4);  // [9] first order[] position of a class
-    // per 64-slot chunk, counts and first positions of the eight classes as 16-bit fields of two 64-bit words
-    // (classes 0-3, 4-7); they live in `hist`, which is free once the records are in their slots
-    unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [2][128]
-    unsigned long long *ch_start = ch_cnt + 256;                                  // [2][128]
+    // per 64-slot chunk, counts and first positions of the four classes as 16-bit fields of a 64-bit word; they
+    // live in `hist`, which is free once the records are in their slots
+    unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [128]
+    unsigned long long *ch_start = ch_cnt + 128;                                  // [128]
 
     const int64_t b = blockIdx.x;
     const int64_t nblocks = gridDim.x;
@@ -415,21 +415,16 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             {
                 const bool todo = valid && s.st != ST_DONE;
                 const int cls = (int)((rk[q < nq ? q : 0] >> RTMI_RK_CLASS_SHIFT) & (RTMI_RK_CLASSES - 1));
-                unsigned long long w0 = 0, w1 = 0, mine = 0;
+                unsigned long long w0 = 0, mine = 0;
 #pragma unroll
                 for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
                     const unsigned long long bk = __ballot(todo && cls == k);
                     if (cls == k)
                         mine = bk;
-                    if (k < 4)
-                        w0 |= (unsigned long long)__popcll(bk) << (16 * k);
-                    else
-                        w1 |= (unsigned long long)__popcll(bk) << (16 * (k - 4));
+                    w0 |= (unsigned long long)__popcll(bk) << (16 * k);
                 }
-                if (lane == 0) {
+                if (lane == 0)
                     ch_cnt[q0 >> 6] = w0;
-                    ch_cnt[128 + (q0 >> 6)] = w1;
-                }
                 if (valid)
                     tnl[q] = todo ? ((uint32_t)cls | ((uint32_t)__popcll(mine & lt_mask) << 3)) : 0xFFFFFFFFu;
             }
@@ -446,30 +441,26 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         if (wib == 0) {
             // lane l owns chunks 2l and 2l+1: exclusive prefix of the counts (16-bit fields, no carry: <= 8128)
             const int c0 = 2 * lane, c1 = 2 * lane + 1;
-            unsigned long long tot[2];
+            const unsigned long long n0 = c0 < nchq ? ch_cnt[c0] : 0ull;
+            const unsigned long long n1 = c1 < nchq ? ch_cnt[c1] : 0ull;
+            unsigned long long in_n = n0 + n1;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned long long n0 = c0 < nchq ? ch_cnt[128 * h + c0] : 0ull;
-                const unsigned long long n1 = c1 < nchq ? ch_cnt[128 * h + c1] : 0ull;
-                unsigned long long in_n = n0 + n1;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const unsigned long long on = __shfl_up(in_n, off, 64);
-                    if (lane >= off)
-                        in_n += on;
-                }
-                tot[h] = __shfl(in_n, 63, 64);
-                const unsigned long long ex_n = in_n - (n0 + n1);
-                if (c0 < nchq)
-                    ch_start[128 * h + c0] = ex_n;
-                if (c1 < nchq)
-                    ch_start[128 * h + c1] = ex_n + n0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long on = __shfl_up(in_n, off, 64);
+                if (lane >= off)
+                    in_n += on;
             }
+            const unsigned long long tot = __shfl(in_n, 63, 64);
+            const unsigned long long ex_n = in_n - (n0 + n1);
+            if (c0 < nchq)
+                ch_start[c0] = ex_n;
+            if (c1 < nchq)
+                ch_start[c1] = ex_n + n0;
             if (lane == 0) {
                 uint32_t run = 0;
                 for (int k = 0; k < RTMI_RK_CLASSES; ++k) {
                     cls_base[k] = run;
-                    run += (uint32_t)((tot[k >> 2] >> (16 * (k & 3))) & 0xFFFFull);
+                    run += (uint32_t)((tot >> (16 * k)) & 0xFFFFull);
                 }
                 cls_base[RTMI_RK_CLASSES] = run;  // records that need the solve loop
             }
@@ -481,7 +472,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const uint32_t v = q < nq ? tnl[q] : 0xFFFFFFFFu;  // class | rank within (chunk, class) << 3
             if (v != 0xFFFFFFFFu) {
                 const int cls = (int)(v & 7u);
-                const uint32_t st = (uint32_t)((ch_start[128 * (cls >> 2) + c] >> (16 * (cls & 3))) & 0xFFFFull);
+                const uint32_t st = (uint32_t)((ch_start[c] >> (16 * cls)) & 0xFFFFull);
                 order[cls_base[cls] + st + (v >> 3)] = (uint16_t)q;
             }
         }
