@@ -339,7 +339,7 @@ def main():
         # (v_rsq/v_rcp_f64: 16), i.e. 16 lanes per clock and SIMD = FP64_VALU_PEAK_TFLOPS / 2 lane-instructions per
         # second over the chip.  Executed instructions come from the same PMC passes (SQ_INSTS_VALU); the useful part
         # is the layer terms the reference's arithmetic needs: 41.7 per travel time on this workload (counted by the
-        # instrumented kernel, profiles/r01m/phase_clocks.txt) x 33 instructions each.
+        # instrumented kernel, profiles/r01n/phase_clocks.txt) x 33 instructions each.
         peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
         res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
                             "useful_term_instr_per_travel_time": 41.7 * 33,
