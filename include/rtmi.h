@@ -136,6 +136,13 @@ int rtmi_init(int device);
 /* Text of the last error of the calling thread ("" if none). */
 const char *rtmi_last_error(void);
 int rtmi_version(void);
+/*
+ * Sticky fault word of the device code: 0, or a bit mask if a kernel ever ran out of one of its bounded waits (the
+ * hand-over ring of the fused kernel is deadlock-free by construction; the bounds exist so that a fault could never
+ * hang the GPU).  The host-pointer entry points check it after their synchronise and fail; callers of the
+ * asynchronous device entry points can poll it after their own synchronise.
+ */
+int rtmi_device_status(void);
 /* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
 int rtmi_device_cus(void);
 /*

@@ -68,6 +68,35 @@ struct Context {
     size_t small_cap = 0;
 };
 
+// Sticky fault word of the fused kernel: pinned host memory mapped into the device (written by a kernel only if one
+// of its bounded waits runs out; read by the host for free).  Allocated once per process, by the first caller.
+struct StatusWord {
+    int *host = nullptr;
+    int *dev = nullptr;
+};
+StatusWord &status_word()
+{
+    static StatusWord w = [] {
+        StatusWord v;
+        int *h = nullptr;
+        if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+            *h = 0;
+            void *d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                v.host = h;
+                v.dev = (int *)d;
+            }
+        }
+        return v;
+    }();
+    return w;
+}
+
+int device_fault(int st)
+{
+    return fail(RTMI_ERR_HIP, "the fused kernel reported an internal scheduling fault (status %d): results are not valid", st);
+}
+
 // Tuning knobs of the fused kernel, overridable from the environment for A/B runs.
 struct Tuning {
     int force_path;      // 0 auto, 1 plain kernel, 2 fused kernel
@@ -212,6 +241,8 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
         if (rc)
             return rc;
         HIP_TRY(hipStreamSynchronize(c.stream));
+        if (int st = rtmi_device_status())
+            return device_fault(st);
         memcpy(timeP, h + nm + 2 * n, n * sizeof(double));
         if (want_p)
             return rtmi_write_rays_dat("rays.dat", vels, depths, nlayers, src_offset, src_depth, h + nm + 3 * n, nsrc);
@@ -239,6 +270,8 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
         HIP_TRY(hipMemcpyAsync(p.data(), d_p, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     }
     HIP_TRY(hipStreamSynchronize(c.stream));
+    if (int st = rtmi_device_status())
+        return device_fault(st);
     if (want_p)
         return rtmi_write_rays_dat("rays.dat", vels, depths, nlayers, src_offset, src_depth, p.data(), nsrc);
     return RTMI_OK;
@@ -369,6 +402,12 @@ int rtmi_set_option(const char *name, int value)
     return RTMI_OK;
 }
 
+int rtmi_device_status(void)
+{
+    const StatusWord &w = status_word();
+    return w.host ? *(volatile int *)w.host : 0;
+}
+
 int rtmi_debug_stamps(unsigned long long *d_stamps)
 {
     tuning().d_stamps = d_stamps;
@@ -407,6 +446,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.d_status = status_word().dev;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
@@ -466,6 +506,8 @@ int rtmi_set_sources(const double *src_offset, const double *src_depth, const do
     if (obs)
         HIP_TRY(hipMemcpyAsync(c.d_set + 2 * n, obs, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
+    if (int st = rtmi_device_status())
+        return device_fault(st);
     c.set_n = nsrc;
     c.set_has_obs = obs != nullptr;
     return RTMI_OK;
@@ -529,6 +571,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.d_status = status_word().dev;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = c.d_set;
         fa.d_src_depth = c.d_set + n;
@@ -554,6 +597,8 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
     HIP_TRY(rtmi_launch_loglike(d_work, gx, d_sd, c.set_n, nmodels, d_out, d_out + nm, c.stream));
     HIP_TRY(hipMemcpyAsync(h + n_in, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
+    if (int st = rtmi_device_status())
+        return device_fault(st);
     memcpy(logL, h + n_in, nm * sizeof(double));
     if (ss)
         memcpy(ss, h + n_in + nm, nm * sizeof(double));
@@ -583,6 +628,7 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.d_status = status_word().dev;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
@@ -667,6 +713,7 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
+        fa.d_status = status_word().dev;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;

@@ -56,6 +56,7 @@ struct FusedArgsT {
     T *d_p_final;           // [nsrc] or NULL (single model only)
     const T *d_obs;         // [nsrc] or NULL
     T *d_partial;           // [nmodels][grid.x] per-workgroup sums of squared residuals
+    int *d_status;                 // sticky fault word (host-mapped) or NULL: a bounded wait of the hand-over ring ran out
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };

@@ -558,6 +558,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                             int guard = 0;  // the slot's previous tenant must have been read
                             while (pl_ready[e] != -(gen - 1) && ++guard < (1 << 22))
                                 __builtin_amdgcn_s_sleep(1);
+                            if (guard >= (1 << 22) && a.d_status)
+                                atomicOr(a.d_status, 1);  // never observed: the ring cannot deadlock (see above)
                             pl_xe[e] = s.xe;
                             pl_x[e] = s.x;
                             pl_xb[e] = s.xb;
@@ -610,6 +612,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         int guard = 0;
                         while (pl_ready[e] != gen && ++guard < (1 << 22))
                             __builtin_amdgcn_s_sleep(1);
+                        if (guard >= (1 << 22) && a.d_status)
+                            atomicOr(a.d_status, 2);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         slot = pl_slot[e];
                         const int ps = pl_state[e];
@@ -699,6 +703,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     finished = (__builtin_amdgcn_readfirstlane(pl_ctl[2]) <= 0 &&
                                 __builtin_amdgcn_readfirstlane(pl_ctl[1]) >= __builtin_amdgcn_readfirstlane(pl_ctl[0])) ||
                                ++spins > (1 << 24);
+                    if (spins > (1 << 24) && a.d_status && lane == 0)
+                        atomicOr(a.d_status, 4);
                     if (!finished)
                         __builtin_amdgcn_s_sleep(4);
                 }

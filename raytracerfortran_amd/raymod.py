@@ -55,6 +55,7 @@ SIGNATURES = {
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
     "rtmi_device_cus": (ctypes.c_int, []),
+    "rtmi_device_status": (ctypes.c_int, []),
     "rtmi_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_device_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
