@@ -228,6 +228,13 @@ int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc);
  */
 int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double *d_den, int64_t n,
                            unsigned long long *d_mismatch, void *stream);
+/*
+ * The same for the single-precision layer term (fp32 path): d_mismatch[0] += mismatches of num/sqrtf(w),
+ * d_mismatch[1] += mismatches of den/sqrtf(w)^3 (2 x uint64, zeroed by the caller); guarded ranges
+ * w in (1e-12, 1], num and den 0 or in (1e-18, 1e18).
+ */
+int rtmi_selftest_fastmath_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
+                               unsigned long long *d_mismatch, void *stream);
 
 /*
  * Diagnostic: while d_stamps != NULL, every fused-kernel launch of rtmi_trace_device runs the instrumented build of

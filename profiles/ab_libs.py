@@ -10,7 +10,9 @@ import raytracerfortran_amd as rt
 from raytracerfortran_amd import raymod
 import bench
 cur = rt.load_library(); rt.init(0)
-prev = raymod.load_library(os.path.join(ROOT, "profiles", "ab_prev", "librtmi.so"))
+prev = ctypes.CDLL(os.path.join(ROOT, "profiles", "ab_prev", "librtmi.so"))  # plain dlopen: older builds may lack newer symbols
+prev.rtmi_init.restype = ctypes.c_int; prev.rtmi_trace_device.restype = ctypes.c_int
+prev.rtmi_trace_device.argtypes = cur.rtmi_trace_device.argtypes
 prev.rtmi_init(0)
 v, d, off, dep = bench.c2_workload(1_000_000)
 dev = "cuda"

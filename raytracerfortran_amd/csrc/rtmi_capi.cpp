@@ -487,6 +487,17 @@ int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double 
     return RTMI_OK;
 }
 
+int rtmi_selftest_fastmath_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
+                               unsigned long long *d_mismatch, void *stream)
+{
+    if (n < 0 || !d_w || !d_num || !d_den || !d_mismatch)
+        return fail(RTMI_ERR_BAD_ARG, "bad argument");
+    if (n == 0)
+        return RTMI_OK;
+    HIP_TRY(rtmi_launch_fastmath_check_f32(d_w, d_num, d_den, n, d_mismatch, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
 int rtmi_set_sources(const double *src_offset, const double *src_depth, const double *obs, int64_t nsrc)
 {
     if (nsrc < 1 || !src_offset || !src_depth)

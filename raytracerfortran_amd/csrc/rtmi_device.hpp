@@ -92,14 +92,22 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool r
 
 // v == 0 or |v| inside (1e-30, 1e30): safe as one factor of a numerator of div_guarded (the product of two
 // such factors stays far from the exponent ranges where v_div_scale / v_div_fixup would act).
-__device__ __forceinline__ bool mag_ok(float) { return true; }  // the fp32 build has no guarded fast path
+__device__ __forceinline__ bool mag_ok(float v)  // single precision: the same idea over a narrower exponent range
+{
+    const float a = fabsf(v);
+    return v == 0.0f || (a > 1e-9f && a < 1e9f);
+}
 __device__ __forceinline__ bool mag_ok(double v)
 {
     const double a = fabs(v);
     return v == 0.0 || (a > 1e-30 && a < 1e30);
 }
 
-__device__ __forceinline__ bool mag_nz(float) { return true; }
+__device__ __forceinline__ bool mag_nz(float v)
+{
+    const float a = fabsf(v);
+    return a > 1e-9f && a < 1e9f;
+}
 __device__ __forceinline__ bool mag_nz(double v)  // as mag_ok, zero excluded: safe as a factor of a denominator
 {
     const double a = fabs(v);
@@ -298,43 +306,24 @@ __device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-9
 
 // One layer term of costFunc and costFunc_Prime with a shared reciprocal:  tf = a / s,  tp = hv / ((s*s)*s),
 // s = sqrt(w).  The square-root iteration already carries h ~ 1/(2s); 2h refined by one Newton step against
-// the final s is the (correctly rounded, Markstein 1990) reciprocal r of s, which serves the first quotient
+// the final s is the correctly rounded reciprocal r of s (Markstein 1990), which serves the first quotient
 // directly and -- cubed, then refined once against the ROUNDED cube s3 the reference divides by -- the
 // second.  Each quotient ends with the same residual correction q' = fma(fma(-d, q, n), r, q) as the plain
-// divide, i.e. it is the correctly rounded n/d whenever r is accurate to about an ulp.  Two v_rcp_f64
-// (quarter rate) and four fma per term are saved against two independent divides.  Bitwise equality with
-// `sqrt` and `/` is checked on the GPU over 2^28 solver-shaped operands (test_fast_math_equals_ieee) and by
-// every parity test; the guards of eval_terms apply unchanged.
-__device__ __forceinline__ void term_guarded(double w, double a, double hv, double &tf, double &tp)
-{
-    const double y = __builtin_amdgcn_rsq(w);
-    double g = w * y;
-    double h = y * 0.5;
-    double e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    double d = __builtin_fma(-g, g, w);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, w);
-    g = __builtin_fma(d, h, g);  // g = sqrt(w), as sqrt_guarded
-    double r = h + h;            // ~ 1/s
-    e = __builtin_fma(-g, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    const double q = a * r;
-    tf = __builtin_fma(__builtin_fma(-g, q, a), r, q);
-    const double s3 = (g * g) * g;
-    double r3 = (r * r) * r;
-    e = __builtin_fma(-s3, r3, 1.0);
-    r3 = __builtin_fma(r3, e, r3);
-    const double q3 = hv * r3;
-    tp = __builtin_fma(__builtin_fma(-s3, q3, hv), r3, q3);
-}
-
+// divide, which returns the correctly rounded n/d when r is the correctly rounded reciprocal.  The one family
+// of divisors for which a refined reciprocal is NOT correctly rounded is the all-ones mantissa (the refinement
+// lands exactly on a rounding tie); there, quotients of "short" numerators (powers of two, small integers) come
+// out one ulp low (`profiles/allones_check.py` finds them).  term_guarded_n therefore also returns whether
+// any of its divisors s, s3 has an all-ones low mantissa word -- one integer compare each, a necessary
+// condition hit by 1 ordinary operand in 2^32 -- and the caller treats that like any other operand outside
+// the guards: the wave re-evaluates with the plain operators.  Two v_rcp_f64 (quarter rate) and two fma per
+// term are saved against two independent divides.  Bitwise equality with `sqrt` and `/` is checked on the
+// GPU (test_fast_math_equals_ieee, incl. the all-ones family with short numerators) and by every parity test.
+//
 // N independent layer terms, statement by statement side by side: the same operations as N calls of
 // term_guarded, written interleaved so that a wave that has its SIMD to itself (the end of a round) has N
 // dependency chains in flight.
 template <int N>
-__device__ __forceinline__ void term_guarded_n(const double (&w)[N], const double (&a)[N], const double (&hv)[N],
+__device__ __forceinline__ bool term_guarded_n(const double (&w)[N], const double (&a)[N], const double (&hv)[N],
                                                double (&tf)[N], double (&tp)[N])
 {
     double y[N], g[N], h[N], e[N], d[N], r[N], q[N], s3[N], r3[N];
@@ -381,7 +370,91 @@ __device__ __forceinline__ void term_guarded_n(const double (&w)[N], const doubl
     RTMI_EACH q[j] = hv[j] * r3[j];
 #pragma unroll
     RTMI_EACH tp[j] = __builtin_fma(__builtin_fma(-s3[j], q[j], hv[j]), r3[j], q[j]);
+    // no divisor with an all-ones low mantissa word (see above): one compare on the maximum of the low words
+    uint32_t mx = 0;
+#pragma unroll
+    RTMI_EACH mx = max(mx, max((uint32_t)__double2loint(g[j]), (uint32_t)__double2loint(s3[j])));
 #undef RTMI_EACH
+    return mx != 0xFFFFFFFFu;
+}
+
+// The single-precision form of term_guarded_n: v_rsq_f32 is good to an ulp, so one coupled iteration and one
+// correction give the correctly rounded square root (checked over EVERY float in the guarded range by
+// rtmi_selftest_fastmath_f32), the rest as in double precision.  w in (1e-12, 1], numerators 0 or in (1e-18, 1e18).
+template <int N>
+__device__ __forceinline__ bool term_guarded_n(const float (&w)[N], const float (&a)[N], const float (&hv)[N],
+                                               float (&tf)[N], float (&tp)[N])
+{
+    float y[N], g[N], h[N], e[N], d[N], r[N], q[N], s3[N], r3[N];
+#define RTMI_EACH for (int j = 0; j < N; ++j)
+#pragma unroll
+    RTMI_EACH y[j] = __builtin_amdgcn_rsqf(w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = w[j] * y[j];
+#pragma unroll
+    RTMI_EACH h[j] = y[j] * 0.5f;
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fmaf(-h[j], g[j], 0.5f);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fmaf(g[j], e[j], g[j]);
+#pragma unroll
+    RTMI_EACH h[j] = __builtin_fmaf(h[j], e[j], h[j]);
+#pragma unroll
+    RTMI_EACH d[j] = __builtin_fmaf(-g[j], g[j], w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fmaf(d[j], h[j], g[j]);
+#pragma unroll
+    RTMI_EACH d[j] = __builtin_fmaf(-g[j], g[j], w[j]);
+#pragma unroll
+    RTMI_EACH g[j] = __builtin_fmaf(d[j], h[j], g[j]);
+#pragma unroll
+    RTMI_EACH r[j] = h[j] + h[j];
+    // two refinements: the first leaves r faithful, the second correctly rounded (which the quotient below needs)
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fmaf(-g[j], r[j], 1.0f);
+#pragma unroll
+    RTMI_EACH r[j] = __builtin_fmaf(r[j], e[j], r[j]);
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fmaf(-g[j], r[j], 1.0f);
+#pragma unroll
+    RTMI_EACH r[j] = __builtin_fmaf(r[j], e[j], r[j]);
+#pragma unroll
+    RTMI_EACH q[j] = a[j] * r[j];
+#pragma unroll
+    RTMI_EACH tf[j] = __builtin_fmaf(__builtin_fmaf(-g[j], q[j], a[j]), r[j], q[j]);
+#pragma unroll
+    RTMI_EACH s3[j] = (g[j] * g[j]) * g[j];
+#pragma unroll
+    RTMI_EACH r3[j] = (r[j] * r[j]) * r[j];
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fmaf(-s3[j], r3[j], 1.0f);
+#pragma unroll
+    RTMI_EACH r3[j] = __builtin_fmaf(r3[j], e[j], r3[j]);
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fmaf(-s3[j], r3[j], 1.0f);
+#pragma unroll
+    RTMI_EACH r3[j] = __builtin_fmaf(r3[j], e[j], r3[j]);
+#pragma unroll
+    RTMI_EACH q[j] = hv[j] * r3[j];
+#pragma unroll
+    RTMI_EACH tp[j] = __builtin_fmaf(__builtin_fmaf(-s3[j], q[j], hv[j]), r3[j], q[j]);
+    // no divisor with an all-ones mantissa
+    uint32_t mx = 0;
+#pragma unroll
+    RTMI_EACH mx = max(mx, max(__float_as_uint(g[j]) & 0x7FFFFFu, __float_as_uint(s3[j]) & 0x7FFFFFu));
+#undef RTMI_EACH
+    return mx != 0x7FFFFFu;
+}
+
+// the word of a value that orders positive numbers like integers
+__device__ __forceinline__ int hi_word(double v) { return __double2hiint(v); }
+__device__ __forceinline__ int hi_word(float v) { return (int)__float_as_uint(v); }
+
+// lower end of the guarded range of w = 1 - p^2 v^2
+template <typename T>
+__device__ __forceinline__ constexpr T guard_w()
+{
+    return std::is_same<T, double>::value ? T(1e-60) : T(1e-12);  // fp32: sqrt(w)^3 must stay a normal number
 }
 
 // One layer term: tf = (hv*x)/s, tp = hv/((s*s)*s), s = sqrt(1 - xx*vv).  Returns the guard of the fast form.
@@ -389,9 +462,13 @@ template <bool FAST, typename T>
 __device__ __forceinline__ bool layer_term(T xx, T x, T hv, T vv, T &tf, T &tp)
 {
     const T w = T(1.0) - xx * vv;
-    if constexpr (FAST && std::is_same<T, double>::value) {
-        term_guarded(w, hv * x, hv, tf, tp);
-        return w > 1e-60;
+    if constexpr (FAST) {
+        const T wa[1] = {w}, aa[1] = {hv * x}, ha[1] = {hv};
+        T f1[1], p1[1];
+        const bool sound = term_guarded_n<1>(wa, aa, ha, f1, p1);
+        tf = f1[0];
+        tp = p1[0];
+        return sound && w > guard_w<T>();
     } else {
         const T s = sqrt(w);
         tf = (hv * x) / s;
@@ -406,15 +483,21 @@ __device__ __forceinline__ bool add_terms(T xx, T x, const T (&hv)[N], const T (
 {
     T tf[N], tp[N];
     bool ok = true;
-    if constexpr (FAST && std::is_same<T, double>::value) {
+    if constexpr (FAST) {
         T w[N], a[N];
+        // every w above the lower end of the guarded range: for positive numbers the order of the values is the
+        // order of their (high) words as integers, so one compare on the minimum serves the group (a negative w
+        // has the sign bit set and fails; a NaN w can only come from a NaN x or velocity, which the caller's
+        // guards on x and on the table catch)
+        int mn = 0x7FFFFFFF;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             w[j] = T(1.0) - xx * vv[j];
             a[j] = hv[j] * x;
-            ok = ok && w[j] > 1e-60;
+            mn = min(mn, hi_word(w[j]));
         }
-        term_guarded_n<N>(w, a, hv, tf, tp);
+        ok = mn > hi_word(guard_w<T>());
+        ok = term_guarded_n<N>(w, a, hv, tf, tp) && ok;
     } else {
 #pragma unroll
         for (int j = 0; j < N; ++j)
@@ -484,13 +567,9 @@ template <bool ROWS = false, typename T>
 __device__ __forceinline__ void eval_f_fp(const LayerTable<T> &t, T x, int nfull, int nfull_wave, T hvl,
                                           T vvl, T R, bool numer_ok, bool busy, T &f, T &fp)
 {
-    if constexpr (std::is_same<T, double>::value) {
-        const bool ok = eval_terms<true, ROWS>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
-        if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
-            eval_terms<false, false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
-    } else {
-        eval_terms<false, ROWS>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);  // fp32: plain IEEE sqrtf and divide
-    }
+    const bool ok = eval_terms<true, ROWS>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp) && numer_ok && mag_ok(x);
+    if (__any(busy && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
+        eval_terms<false, false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
 }
 
 // Solver state of one source (one lane).

@@ -74,6 +74,8 @@ hipError_t rtmi_launch_trace_f32(const rtmi::TraceArgsT<float> *args, int nmodel
                                  hipStream_t stream);
 hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
                              int waves_per_simd, int *grid_x_out, hipStream_t stream);
+hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
+                                          unsigned long long *d_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,
                                       unsigned long long *d_out, hipStream_t stream);
 int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);

@@ -821,12 +821,14 @@ __global__ void fastmath_check_kernel(const double *__restrict__ w, const double
         const double d = num[i] / den[i];
         bad_d += (__double_as_longlong(c) != __double_as_longlong(d));
         // the shared-reciprocal layer term against sqrt and two plain divides (num[i] plays H*V*x, den[i] H*V)
-        double tf, tp;
-        term_guarded(w[i], num[i], den[i], tf, tp);
+        const double wa[1] = {w[i]}, na[1] = {num[i]}, da[1] = {den[i]};
+        double tf[1], tp[1];
+        const bool sound = term_guarded_n<1>(wa, na, da, tf, tp);  // false: the kernels would take the plain operators
         const double tf_ref = num[i] / b;
         const double tp_ref = den[i] / ((b * b) * b);
-        bad_t += (__double_as_longlong(tf) != __double_as_longlong(tf_ref)) +
-                 (__double_as_longlong(tp) != __double_as_longlong(tp_ref));
+        if (sound)
+            bad_t += (__double_as_longlong(tf[0]) != __double_as_longlong(tf_ref)) +
+                     (__double_as_longlong(tp[0]) != __double_as_longlong(tp_ref));
     }
     if (bad_s)
         atomicAdd(&out[0], bad_s);
@@ -834,6 +836,30 @@ __global__ void fastmath_check_kernel(const double *__restrict__ w, const double
         atomicAdd(&out[1], bad_d);
     if (bad_t)
         atomicAdd(&out[2], bad_t);
+}
+
+// single precision: the layer term against sqrtf and two plain divides; out[0] += mismatches of num/sqrt(w),
+// out[1] += mismatches of den/sqrt(w)^3
+__global__ void fastmath_check_kernel_f32(const float *__restrict__ w, const float *__restrict__ num,
+                                          const float *__restrict__ den, int64_t n, unsigned long long *out)
+{
+    unsigned long long bad_f = 0, bad_p = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wa[1] = {w[i]}, na[1] = {num[i]}, da[1] = {den[i]};
+        float tf[1], tp[1];
+        const bool sound = term_guarded_n<1>(wa, na, da, tf, tp);
+        const float s = sqrtf(w[i]);
+        const float tf_ref = num[i] / s;
+        const float tp_ref = den[i] / ((s * s) * s);
+        if (sound) {
+            bad_f += (__float_as_uint(tf[0]) != __float_as_uint(tf_ref));
+            bad_p += (__float_as_uint(tp[0]) != __float_as_uint(tp_ref));
+        }
+    }
+    if (bad_f)
+        atomicAdd(&out[0], bad_f);
+    if (bad_p)
+        atomicAdd(&out[1], bad_p);
 }
 
 }  // namespace rtmi
@@ -1032,6 +1058,13 @@ extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args,
                                             int num_cus, int waves_per_simd, int *grid_x_out, hipStream_t stream)
 {
     return launch_fused_t<float>(*args, nmodels, max_nlayers, num_cus, waves_per_simd, grid_x_out, stream);
+}
+
+extern "C" hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den,
+                                                     int64_t n, unsigned long long *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rtmi::fastmath_check_kernel_f32, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, d_out);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
     "rtmi_debug_stamps": (ctypes.c_int, [_vp]),
     "rtmi_selftest_fastmath": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    "rtmi_selftest_fastmath_f32": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     "rtmi_write_rays_dat": (ctypes.c_int, [ctypes.c_char_p, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int64]),
 }
 
@@ -378,6 +379,22 @@ def trace_batch_device(vels, depths, nlayers, src_offset, src_depth, timeP=None,
                                        _ptr(timeP, f64, "timeP"), _ptr(obs, f64, "obs"), _ptr(sd, f64, "sd"),
                                        _ptr(logL, f64, "logL"), _ptr(work, f64, "work"), _stream_ptr(stream)))
     return timeP, logL
+
+
+def selftest_fastmath_f32(w, num, den):
+    """(num/sqrt(w), den/sqrt(w)^3) mismatch counts of the single-precision guarded layer term vs sqrtf and the plain
+    divides on the given float32 CUDA tensors (rtmi_selftest_fastmath_f32)."""
+    import torch
+    lib = load_library()
+    n = int(w.numel())
+    if num.numel() != n or den.numel() != n:
+        raise ValueError("size mismatch")
+    out = torch.zeros(2, dtype=torch.int64, device=w.device)
+    f32 = torch.float32
+    _check(lib.rtmi_selftest_fastmath_f32(_ptr(w, f32, "w"), _ptr(num, f32, "num"), _ptr(den, f32, "den"), n,
+                                          _ptr(out, torch.int64, "out"), _stream_ptr(None)))
+    torch.cuda.synchronize()
+    return int(out[0]), int(out[1])
 
 
 def selftest_fastmath(w, num, den):

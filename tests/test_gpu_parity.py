@@ -317,6 +317,81 @@ def test_fast_math_equals_ieee(rt):
     assert (total_s, total_d, total_t) == (0, 0, 0)
 
 
+def test_fast_math_all_ones_divisors(rt):
+    """Markstein's exception: for a divisor with an all-ones mantissa a refined reciprocal is not correctly rounded and
+    quotients of short numerators (powers of two, small integers, multiples of the divisor) come out one ulp low.
+    The shared-reciprocal layer term flags such divisors (the kernels then take the plain operators): over the whole
+    family -- every w whose square root has an all-ones mantissa, short and random numerators -- nothing that the
+    fast form accepts differs from sqrt and the plain divides."""
+    import torch
+    from raytracerfortran_amd import raymod
+    ws = []
+    for k in range(0, 60):
+        g = np.nextafter(np.float64(2.0) ** (-k), 0.0)
+        w0 = g * g
+        for w in (np.nextafter(w0, 0), w0, np.nextafter(w0, 1), np.nextafter(np.nextafter(w0, 1), 1)):
+            if np.sqrt(w) == g and 1e-60 < w <= 1.0:
+                ws.append(w)
+    ws = np.unique(np.array(ws))
+    assert ws.size >= 100
+    spec = np.concatenate([2.0 ** np.arange(-40, 41), np.arange(1, 200, dtype=np.float64), 1.0 / np.arange(1, 200)])
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    tot = np.zeros(3, dtype=np.int64)
+    for w in ws:
+        gq = np.sqrt(w)
+        nums = np.concatenate([spec, gq * spec[:81], gq * gq * spec[:81], (gq ** 3) * spec[:81]])
+        rnd = torch.exp(40.0 * (torch.rand(1 << 16, dtype=torch.float64, device="cuda", generator=gen) - 0.5))
+        nt = torch.cat([torch.tensor(nums, device="cuda"), rnd])
+        wt = torch.full((nt.numel(),), float(w), dtype=torch.float64, device="cuda")
+        tot += np.array(raymod.selftest_fastmath(wt, nt, nt.flip(0).contiguous()))
+    assert tot[2] == 0 and tot[0] == 0, tot
+
+
+def test_fast_math_equals_ieee_f32(rt):
+    """The single-precision guarded layer term returns the bits of sqrtf and the plain divides: for EVERY float w of
+    the guarded range (1e-12, 1] with unit numerators (i.e. 1/sqrt(w) and 1/sqrt(w)^3 exhaustively), and for random
+    numerators over their guarded range."""
+    import torch
+    from raytracerfortran_amd import raymod
+    lo = int(np.float32(1.0000001e-12).view(np.uint32))
+    hi = int(np.float32(1.0).view(np.uint32))
+    tot = [0, 0]
+    step = 1 << 26
+    for start in range(lo, hi + 1, step):
+        bits = torch.arange(start, min(start + step, hi + 1), dtype=torch.int64, device="cuda").to(torch.int32)
+        w = bits.view(torch.float32)
+        one = torch.ones_like(w)
+        a, b = raymod.selftest_fastmath_f32(w.contiguous(), one, one)
+        tot[0] += a
+        tot[1] += b
+    assert tot == [0, 0], tot
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = 1 << 25
+    for trial in range(4):
+        u = torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+        e = torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+        if trial == 0:    # solver-like: w = 1 - (pv)^2, numerators H V p and H V
+            pv = u * (1.0 - 1e-6)
+            w = 1.0 - pv * pv
+            den = (50.0 + 3000.0 * e) * (1500.0 + 8500.0 * torch.rand(n, dtype=torch.float32, device="cuda", generator=g))
+            num = den * (pv / 6000.0)
+        elif trial == 1:  # whole guarded range, log-uniform
+            w = torch.exp(-27.0 * u)
+            den = torch.exp(82.0 * (e - 0.5))
+            num = torch.exp(82.0 * (u - 0.5)) * torch.sign(e - 0.3)
+        elif trial == 2:  # zeros and ones among ordinary values
+            w = torch.where(u < 0.1, torch.ones_like(u), u * 0.999 + 1e-3)
+            den = torch.where(e < 0.1, torch.zeros_like(e), e + 1e-3)
+            num = torch.where(u > 0.9, torch.zeros_like(u), u - 0.5)
+        else:             # near-critical layers
+            w = torch.exp(-20.0 * u) + 2e-12
+            den = 1e5 + 1e7 * e
+            num = den * 1e-4 * torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+        w = torch.clamp(w, 1.1e-12, 1.0)
+        a, b = raymod.selftest_fastmath_f32(w.contiguous(), num.contiguous(), den.contiguous())
+        assert (a, b) == (0, 0), (trial, a, b)
+
+
 def test_fused_kernel_many_layers_and_host_path(rt, O):
     """dff_ takes the fused kernel for NSrc >= 8192; with 300 and 1024 interfaces the sort bins are
     proportional and the LDS share of a wave shrinks (several rounds per wave)."""
