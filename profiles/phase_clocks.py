@@ -35,13 +35,11 @@ sol = (s[:, 2] - s[:, 1]).astype(float)
 for x in range(8):
     g = sol[x::8]
     print(f"blockIdx%8={x}: solve mean {g.mean():9.0f} min {g.min():9.0f} max {g.max():9.0f}")
-# per-block work estimate from the oracle's counters (evaluations x layers)
-from oracle import oracle as O
+# per-block work proxy: sum over the block's sources of the layer index of the source (layers per evaluation)
 nb = len(s)
 nch = (n + 63) // 64
 work = np.zeros(nb)
-tt, p, nl = O.oracle_dff(v, d, off, dep, want_p=True)
-# cheap proxy: sum of nl per block (layers per evaluation); evaluations per source are not exported
+nl = 1 + np.searchsorted(d, dep, side="right")  # the model's interfaces are sorted: layer index of each source
 for b in range(nb):
     idx = np.concatenate([np.arange(c * 64, min((c + 1) * 64, n)) for c in range(b, nch, nb)])
     work[b] = nl[idx].sum()
