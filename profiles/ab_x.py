@@ -12,7 +12,7 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     v, d, off, dep = bench.c2_workload(N)
     dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
     out = torch.empty(off.size, dtype=torch.float64, device=dev)
-    settings = [("t%d p%d r%d m%d" % (t, pa, r, m), dict(tail_group=t, promote_age=pa, retire_max=r, refill_min=m)) for t in (0, 256) for pa in (0, 8, 10, 12, 16) for r in (8,) for m in (8, 16, 24)]
+    settings = [("m%d r%d" % (m, r), dict(refill_min=m, retire_max=r)) for m in (12, 16, 20, 24, 32, 40) for r in (8, 12)]
     res = {n: [] for n, _ in settings}
     for r in range(7):
         for n, val in settings:

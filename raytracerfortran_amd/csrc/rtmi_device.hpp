@@ -33,6 +33,7 @@ enum : int {
 // Models of up to RTMI_ROWS_MAX_NL interfaces also get the pair table once per stack height ("rows", see LayerTable);
 // `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
 #define RTMI_ROWS_MAX_NL 20
+#define RTMI_HINT_MAX_NL 512  // deeper models: no ordering of the bisection sources by expected evaluations
 #define RTMI_TABLE_ELEMS(nlayers, rows) \
     (((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(nlayers) + 1) / 2 * 2 + \
      ((rows) ? (size_t)2 * ((nlayers) + 1) * ((nlayers) + 1) : 0))
@@ -57,7 +58,7 @@ struct LayerTable {
     T *PS;    // PS[i]   ((H0/V0 + H1/V1) + ...) + Hi/Vi            i < nlayers
     T *VMAX;  // VMAX[i] max(V[0..i])                               i <= nlayers
     T *VMI;   // VMI[i]  1/VMAX[i]                                  i <= nlayers
-    T *Q;     // scratch H[i]/V[i]
+    T *Q;     // scratch: H[i]/V[i] while the table is built, then the index of the fastest layer of the stack 0..i
     T *PA;    // } scheduling hint only (trip_class): the offset the rest of the stack covers when the ray runs
     T *PC;    // } critical in its fastest layer, PA[il] + hl * PC[il], and that layer's thickness PH[il] (0: it
     T *PH;    // } is the source's own layer, thickness hl)                             1 <= il <= nlayers
@@ -149,12 +150,15 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
     if (threadIdx.x == 0) {
         T s = t.Q[0];
         T m = t.V[0];
+        int jm = 0;  // first layer that carries the maximum (for the scheduling hint below)
         bool ok = mag_ok(t.HV[0]) && mag_ok(t.H[0]) && mag_nz(m);
         t.PS[0] = s;
         t.VMAX[0] = m;
         t.HVOK[0] = ok ? T(1.0) : T(0.0);
+        t.Q[0] = T(0.0);
         for (int i = 1; i <= nlayers; ++i) {
             const T v = t.V[i];
+            jm = (v > m) ? i : jm;
             m = (v > m) ? v : m;  // maxval(): order-free
             t.VMAX[i] = m;
             if (i < nlayers) {
@@ -163,6 +167,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
                 ok = ok && mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v);
                 t.HVOK[i] = ok ? T(1.0) : T(0.0);
             }
+            t.Q[i] = (T)jm;  // Q[i] has served: it now holds the index of the fastest layer of the stack 0..i
         }
     }
     __syncthreads();
@@ -184,17 +189,25 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         // offset is  R ~ A + H_j / sqrt(1 - (p vmax)^2)  with A the offset covered by the other layers at
         // p = 1/vmax, so (R - A) / H_j tells how close to critical the solution lies.  Single precision: this
         // only orders the work, no result depends on it.
+        // The table costs O(nlayers^2) operations per workgroup (approximate single-precision reciprocal and
+        // reciprocal square root: a few instructions per pair of layers).
         for (int il = 1 + (int)threadIdx.x; il <= nlayers; il += blockDim.x) {
-            const float vmax = (float)t.VMAX[il];
-            int j = 0;
-            while (j < il && (float)t.V[j] != vmax)
-                ++j;  // first layer of the stack (own layer = il included) with the maximum velocity
+            if (nlayers > RTMI_HINT_MAX_NL) {
+                // very deep models: one class for all bisection sources (measured at 1024 interfaces: ordering by
+                // expected evaluations mixes the layer counts inside a wave, which costs more than it returns)
+                t.PA[il] = T(INFINITY);
+                t.PC[il] = T(0.0);
+                t.PH[il] = T(0.0);
+                continue;
+            }
+            const float inv_vmax = __builtin_amdgcn_rcpf((float)t.VMAX[il]);
+            const int j = (int)t.Q[il];  // first layer of the stack (own layer = il included) with the maximum velocity
             float a = 0.0f, c = 0.0f;
             for (int i = 0; i <= il; ++i) {
                 if (i == j)
                     continue;
-                const float pv = fminf((float)t.V[i] / vmax, 0.999999f);
-                const float r = pv * __frsqrt_rn(1.0f - pv * pv);  // tan of the ray angle in layer i at p = 1/vmax
+                const float pv = fminf((float)t.V[i] * inv_vmax, 0.999999f);
+                const float r = pv * __builtin_amdgcn_rsqf(1.0f - pv * pv);  // tan of the ray angle in layer i at p = 1/vmax
                 if (i < il)
                     a += (float)t.H[i] * r;
                 else
