@@ -455,6 +455,37 @@ def test_trace_batch_device_and_loglike(rt, O):
         assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
 
 
+def test_batch_small_leading_dimension_rows(rt, O):
+    """Batch of models with 1..11 interfaces in a leading dimension of 12: the launch is small enough for the layer
+    tables with one row per stack height, and every model carves its own (ragged) rows."""
+    import torch
+    rng = np.random.default_rng(77)
+    nm, n, ld = 24, 20011, 12
+    off, dep = rng.uniform(1, 9000, n), rng.uniform(1, 9000, n)
+    V, D, NL = np.zeros((nm, ld)), np.zeros((nm, ld)), np.zeros(nm, np.int32)
+    for m in range(nm):
+        k = 2 + m % 11  # 2..12 velocities = 1..11 interfaces
+        D[m, :k - 1] = np.sort(rng.uniform(50.0, 8000.0, k - 1))
+        V[m, :k] = rng.uniform(1500, 9000, k)
+        NL[m] = k - 1
+    obs = rng.uniform(0.1, 3.0, n)
+    sd = np.full(nm, 0.05)
+    dev = "cuda"
+    args = [torch.tensor(a, device=dev) for a in (V, D, NL, off, dep)]
+    try:
+        rt.set_option("path", 2)
+        T, L = rt.trace_batch_device(*args, obs=torch.tensor(obs, device=dev), sd=torch.tensor(sd, device=dev))
+    finally:
+        rt.set_option("path", 0)
+    torch.cuda.synchronize()
+    T, L = T.cpu().numpy(), L.cpu().numpy()
+    for m in range(nm):
+        ref = O.oracle_dff(V[m, :NL[m] + 1], D[m, :NL[m]], off, dep)
+        assert compare_times(T[m], ref, TOL) == 0.0, m
+        ll = O.oracle_loglhood_rt(obs, ref, sd[m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_batch_paths_agree_c3_shape(rt, O, path):
     """BASELINE config 3 shape: 32 models (k = 2..10) over 1e4 shared sources, travel times and fused logL,
