@@ -26,28 +26,28 @@
 //            sort of the records in LDS by DESCENDING layer index (ballots, no atomics: slots are the
 //            same on every run), so that a wave's layer loop has one trip count at any time; straight
 //            top-layer rays are finished here;
-//        a2. first evaluation of every record at full occupancy: GetPTime's branch (:136-153), which
-//            also splits the records into a long class (bisection first) and a short class (Newton
-//            from p0); sources converged at p0 are done;
-//        a3. the solve order (long class, then short class, each by descending layer index) is built
-//            from per-chunk ballots, deterministically;
+//        a2. first evaluation of every record at full occupancy: GetPTime's branch (:136-153); sources
+//            converged at p0 are done; every other one gets a class by the evaluations it is going to need
+//            (Newton-only sources last; bisection sources by a closed-form estimate, trip_class in
+//            rtmi_device.hpp, which only orders the work), and the per-chunk class counts are taken here;
+//        a3. the solve order (class by class, most evaluations first, each by descending layer index) is
+//            built from those counts and one 64-lane scan, deterministically;
 //        b.  solve: every wave pulls records from the workgroup's queue; a lane that finishes takes the
 //            next record once `refill_min` lanes are idle, so the evaluation loop runs with most lanes
 //            live instead of waiting for the slowest source; no global memory traffic inside the loop
-//            (records and results live in LDS).  The phase is bound by its critical path (a source may
-//            need 38 evaluations in sequence, and a trip of a wave that shares its SIMD with three
-//            others takes 2-3x the wall time of a wave running alone), so waves 0..3 -- one per SIMD --
-//            are "express" waves and the other waves hand them, through an LDS
-//            ring, every source that has already taken `promote_age` trips and, in the drain, their last
-//            `retire_max` live lanes (resumable lane states); `tail_group` steers the last records of the
-//            queue to the first wave groups;
+//            (records and results live in LDS).  Longest first keeps the end of the round short.  Waves
+//            0..3 -- one per SIMD, the oldest waves, which the issue arbiter prefers -- are "express"
+//            waves: the other waves hand them, through an LDS ring, every source that has already taken
+//            `promote_age` trips and, in the drain, their last `retire_max` live lanes (resumable lane
+//            states); `tail_group` steers the last records of the queue to the first wave groups.
+//            Wave-uniform values are kept scalar on purpose (readfirstlane / readlane / DPP);
 //        c.  time: t = sum H_i/(V_i cos_i) from the final ray parameters in sorted order, written to
 //            timeP (the only HBM write); with observations the squared residuals are reduced per
 //            workgroup in a fixed order (deterministic logL).
 //      HBM traffic stays at the algorithmic 24 B per source (offset/depth are read a second time from
 //      L2 in the sort's second pass); no workspace, no global atomics.
 //  Both kernels are templates on the scalar type: double is the reference's precision, float the
-//  fp32 path of BASELINE config 5 (no guarded fast path there: plain IEEE sqrtf and divide).
+//  fp32 path of BASELINE config 5 (its layer term has a guarded form of its own, everything else is IEEE).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
