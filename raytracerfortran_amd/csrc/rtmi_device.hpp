@@ -151,6 +151,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         T s = t.Q[0];
         T m = t.V[0];
         int jm = 0;  // first layer that carries the maximum (for the scheduling hint below)
+        bool sorted = true;  // interfaces in non-decreasing order (no NaN): which_layer may search by bisection
         bool ok = mag_ok(t.HV[0]) && mag_ok(t.H[0]) && mag_nz(m);
         t.PS[0] = s;
         t.VMAX[0] = m;
@@ -166,9 +167,11 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
                 t.PS[i] = s;
                 ok = ok && mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v);
                 t.HVOK[i] = ok ? T(1.0) : T(0.0);
+                sorted = sorted && (t.D[i] >= t.D[i - 1]);
             }
             t.Q[i] = (T)jm;  // Q[i] has served: it now holds the index of the fastest layer of the stack 0..i
         }
+        t.HVOK[nlayers] = (sorted && t.D[0] == t.D[0]) ? T(1.0) : T(0.0);  // spare entry: the "sorted" flag
     }
     __syncthreads();
     if (t.HWR) {
@@ -260,17 +263,34 @@ __device__ __forceinline__ int wave_max_i32(int v)
 
 // whichLayer (:9-32): 1-based index of the first interface strictly below z; nlayers+1 below the
 // last one; nlayers when z sits exactly on the last interface (diff == 0 is neither > 0 nor < 0).
-// Wave-uniform loop with early exit; every lane of the wave must call it.
+// Every lane of the wave must call it (wave-uniform loops).  With the interfaces in non-decreasing order
+// (the flag stage_model leaves in HVOK[nlayers]) the first interface below z is found by bisection:
+// "first i with depths(i) > z" is then the number of interfaces <= z.  Unsorted interfaces take the
+// reference's own scan.
 template <typename T>
 __device__ __forceinline__ int which_layer(const LayerTable<T> &t, int nlayers, T z)
 {
     int nl = 0;
-    for (int i = 0; i < nlayers; ++i) {
-        const bool below = t.D[i] > z;  // == (depths(i) - dph > 0)
-        if (below && nl == 0)
-            nl = i + 1;
-        if (__all(nl != 0))
-            break;
+    if (t.HVOK[nlayers] != T(0.0)) {
+        int lo = 0, hi = nlayers;  // the count c of interfaces <= z lies in [lo, hi]
+        while (__any(lo < hi)) {
+            const bool act = lo < hi;
+            const int mid = (lo + hi) >> 1;
+            const bool le = t.D[act ? mid : 0] <= z;
+            lo = (act && le) ? mid + 1 : lo;
+            hi = (act && !le) ? mid : hi;
+        }
+        nl = lo < nlayers ? lo + 1 : 0;
+        if (z != z)
+            nl = 0;  // NaN depth: every comparison of the reference is false
+    } else {
+        for (int i = 0; i < nlayers; ++i) {
+            const bool below = t.D[i] > z;  // == (depths(i) - dph > 0)
+            if (below && nl == 0)
+                nl = i + 1;
+            if (__all(nl != 0))
+                break;
+        }
     }
     if (nl == 0)
         nl = (t.D[nlayers - 1] - z < T(0.0)) ? nlayers + 1 : nlayers;

@@ -645,6 +645,37 @@ def test_many_layers(rt, O):
         rt.dff(np.ones(1026) * 3000, np.arange(1, 1026.0), 1025, [1.0], [1.0], 1)
 
 
+def test_unsorted_and_tied_interfaces(rt, O):
+    """whichLayer is the reference's scan ("first interface below z"); the kernels search by bisection only when the
+    interfaces are in non-decreasing order.  Tied interfaces (zero-thickness layers) keep the bisection, interfaces
+    out of order take the scan: both return the oracle's bits, through the plain and the fused kernel."""
+    import torch
+    rng = np.random.default_rng(4242)
+    for case in range(6):
+        k = int(rng.integers(4, 14))
+        d = np.sort(rng.uniform(100.0, 6000.0, k - 1))
+        if case % 2 == 0:
+            d[rng.integers(1, k - 1)] = d[0]            # out of order (a shallow interface listed late)
+            if case == 4:
+                d = d[::-1].copy()                      # fully reversed
+        else:
+            j = int(rng.integers(1, k - 1))
+            d[j] = d[j - 1]                              # a tie: zero-thickness layer
+        v = rng.uniform(1500, 8000, k)
+        n = 30011
+        off, dep = rng.uniform(0.0, 9000.0, n), rng.uniform(0.5, 7000.0, n)
+        dep[:50] = rng.choice(d, 50)                     # sources exactly on interfaces
+        ref = O.oracle_dff(v, d, off, dep)
+        for path in (1, 2):
+            try:
+                rt.set_option("path", path)
+                t = rt.trace_device(torch.tensor(v, device="cuda"), torch.tensor(d, device="cuda"),
+                                    torch.tensor(off, device="cuda"), torch.tensor(dep, device="cuda")).cpu().numpy()
+            finally:
+                rt.set_option("path", 0)
+            assert np.array_equal(t, ref, equal_nan=True), (case, path, int((t != ref).sum()))
+
+
 def test_fused_kernel_random_model_soak(rt, O):
     """Random models of every shape the sampler's prior can draw and a few it cannot (monotone, low-velocity zones,
     tied maxima, thin and thick layers, 1..60 interfaces, velocities over three decades), source sets from 9 000 to
