@@ -156,6 +156,7 @@ int ensure_ready_locked(Context &c)
     c.cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(rtmi_prepare_kernels());
+    (void)status_word();  // one-time pinned allocation: here, not inside a caller's stream capture
     c.ready = true;
     return RTMI_OK;
 }
