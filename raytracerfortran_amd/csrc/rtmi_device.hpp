@@ -115,6 +115,16 @@ __device__ __forceinline__ bool mag_nz(double v)  // as mag_ok, zero excluded: s
     return a > 1e-30 && a < 1e30;
 }
 
+// The value lane `j` (wave-uniform) holds, in every lane.
+__device__ __forceinline__ double wave_readlane(double v, int j)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+__device__ __forceinline__ float wave_readlane(float v, int j)
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), j));
+}
+
 // Derive the table of one model (whole workgroup; ends with a barrier).  Roundings are the reference's:
 //   H(i) = depths(i) - depths(i-1)            InsertLayer :67
 //   (H*V) and (V*V) as separate products      costFunc :195, costFunc_Prime :214-219
@@ -147,31 +157,58 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         t.VV[t.nul] = T(0.0);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        T s = t.Q[0];
-        T m = t.V[0];
-        int jm = 0;  // first layer that carries the maximum (for the scheduling hint below)
-        bool sorted = true;  // interfaces in non-decreasing order (no NaN): which_layer may search by bisection
-        bool ok = mag_ok(t.HV[0]) && mag_ok(t.H[0]) && mag_nz(m);
-        t.PS[0] = s;
-        t.VMAX[0] = m;
-        t.HVOK[0] = ok ? T(1.0) : T(0.0);
-        t.Q[0] = T(0.0);
-        for (int i = 1; i <= nlayers; ++i) {
-            const T v = t.V[i];
-            jm = (v > m) ? i : jm;
-            m = (v > m) ? v : m;  // maxval(): order-free
-            t.VMAX[i] = m;
-            if (i < nlayers) {
-                s = s + t.Q[i];
-                t.PS[i] = s;
-                ok = ok && mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v);
-                t.HVOK[i] = ok ? T(1.0) : T(0.0);
-                sorted = sorted && (t.D[i] >= t.D[i - 1]);
+    if (threadIdx.x < 64) {
+        // The sequential part -- running maximum, left-to-right sum, running flags -- over the lanes of wave 0:
+        // every lane loads its layer, then one scalar loop walks the lanes with readlane (no LDS round trip per
+        // layer); the running values are the same in every lane, lane j keeps what they are after layer j.
+        const int lane = threadIdx.x;
+        T s = T(0.0), m = T(0.0);
+        int jm = 0;           // first layer that carries the maximum (for the scheduling hint below)
+        bool okrun = true;    // H, H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
+        bool sorted = true;   // interfaces in non-decreasing order (no NaN): which_layer may search by bisection
+        for (int base = 0; base <= nlayers; base += 64) {
+            const int i = base + lane;
+            const bool in = i <= nlayers, inl = i < nlayers;
+            const T v = in ? t.V[i] : T(0.0), q = inl ? t.Q[i] : T(0.0);
+            const bool ok_l = !inl || (mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v));
+            const bool so_l = !(inl && i >= 1) || (t.D[i] >= t.D[i - 1]);
+            T vmax_l = T(0.0), ps_l = T(0.0);
+            int jm_l = 0;
+            const int cnt = nlayers + 1 - base < 64 ? nlayers + 1 - base : 64;
+            for (int j = 0; j < cnt; ++j) {
+                const T vj = wave_readlane(v, j), qj = wave_readlane(q, j);
+                const int ij = base + j;
+                if (ij == 0) {
+                    m = vj;
+                    s = qj;
+                } else {
+                    jm = (vj > m) ? ij : jm;
+                    m = (vj > m) ? vj : m;  // maxval(): order-free
+                    if (ij < nlayers)
+                        s = s + qj;         // sum(depths/vp) left to right
+                }
+                if (lane == j) {
+                    vmax_l = m;
+                    ps_l = s;
+                    jm_l = jm;
+                }
             }
-            t.Q[i] = (T)jm;  // Q[i] has served: it now holds the index of the fastest layer of the stack 0..i
+            const unsigned long long bad = __ballot(!ok_l);
+            const int firstbad = bad ? __ffsll((long long)bad) - 1 : 64;
+            const bool hvok_l = okrun && lane < firstbad;
+            okrun = okrun && bad == 0ull;
+            sorted = sorted && __ballot(!so_l) == 0ull;
+            if (in) {
+                t.VMAX[i] = vmax_l;
+                t.Q[i] = (T)jm_l;  // Q[i] has served: it now holds the index of the fastest layer of the stack 0..i
+            }
+            if (inl) {
+                t.PS[i] = ps_l;
+                t.HVOK[i] = hvok_l ? T(1.0) : T(0.0);
+            }
         }
-        t.HVOK[nlayers] = (sorted && t.D[0] == t.D[0]) ? T(1.0) : T(0.0);  // spare entry: the "sorted" flag
+        if (lane == 0)
+            t.HVOK[nlayers] = (sorted && t.D[0] == t.D[0]) ? T(1.0) : T(0.0);  // spare entry: the "sorted" flag
     }
     __syncthreads();
     if (t.HWR) {
