@@ -848,6 +848,28 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     }
 }
 
+// lane_advance for a lane in ST_INIT (the fused kernel's first-evaluation pass): GetPTime's branch (:136-153) after
+// cf = f(p0), cfp = f'(p0).  Same operations on the same operands as lane_advance.
+template <typename T>
+__device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp)
+{
+    const T q = f / fp;                        // cf/cfp (:138)
+    const bool neg = f < T(0.0);
+    const bool small = fabs(f) < T(0.1);       // abs(fx) < tol (:287) of solve's first trip
+    const T check_x = s.xe - q;                // check_x = p0 - cf/cfp (:138)
+    const bool newton = neg || check_x < s.safe;  // (:139-144) Newton straight from p0, else bisection first (:145-148)
+    T xnew = s.xe - q;                         // solve's first trip: x = p0 - deltax (:298)
+    if (xnew > s.vmi)
+        xnew = s.clampv;                       // (:299-304)
+    const bool conv = newton && small;
+    const bool go = newton && !small;
+    s.x = go ? xnew : s.x;                     // converged at p0: x stays p0
+    s.xe = go ? xnew : (newton ? s.xe : T(1e-10));
+    s.k = go ? 2 : (newton ? 1 : s.k);
+    s.conv = conv ? true : s.conv;
+    s.st = conv ? ST_DONE : (go ? ST_NEWTON : ST_BIS0);
+}
+
 // lane_advance for the fused kernel's solve loop (states BIS0, BIS, NEWTON, FINAL; never INIT), one block per state,
 // each skipped when no lane of the wave is in that state.  With the longest-first solve order the lanes of a wave
 // are mostly in the same phase of their solves, so most trips execute one block; inside a block the updates are

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             else
                 eval_f_fp<false>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
             if (live)
-                lane_advance<ADV_INIT_ONLY>(s, f, fp);
+                lane_advance_init(s, f, fp);
             if (valid) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
