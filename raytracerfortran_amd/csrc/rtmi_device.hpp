@@ -708,6 +708,7 @@ __device__ __forceinline__ T initial_p0_impl(const LayerTable<T> &t, int il, T R
     // sum(sqrt(1-(p0**2)*(vp+1)**2)) is NaN  <=>  (p0*p0)*(vmax+1)^2 > 1  (monotone in V; the
     // subtraction from 1 has the exact sign).
     int guard = 0;
+#pragma unroll 1
     while (!((p0 * p0) * vm1sq <= T(1.0))) {
         p0 = p0 / T(2.0);
         if (++guard > 2200 || p0 != p0)

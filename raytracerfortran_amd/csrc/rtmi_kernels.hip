@@ -539,6 +539,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     int base = -1;
                     if (lane == 0) {
                         int tl = pl_ctl[0];
+#pragma unroll 1
                         for (;;) {
                             if (tl - pl_ctl[1] + np > RTMI_POOL)  // claimed-but-unread slots count as occupied
                                 break;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                             const int i = base + __popcll(pm & lt_mask);
                             const int e = i & (RTMI_POOL - 1), gen = i / RTMI_POOL + 1;
                             int guard = 0;  // the slot's previous tenant must have been read
+#pragma unroll 1
                             while (pl_ready[e] != -(gen - 1) && ++guard < (1 << 22))
                                 __builtin_amdgcn_s_sleep(1);
                             if (guard >= (1 << 22) && a.d_status)
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 int base = 0, take = 0;
                 if (lane == 0) {
                     int head = pl_ctl[1];
+#pragma unroll 1
                     for (;;) {
                         const int avail = pl_ctl[0] - head;
                         take = avail < nidle ? avail : nidle;
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         const int i = base + r;
                         const int e = i & (RTMI_POOL - 1), gen = i / RTMI_POOL + 1;
                         int guard = 0;
+#pragma unroll 1
                         while (pl_ready[e] != gen && ++guard < (1 << 22))
                             __builtin_amdgcn_s_sleep(1);
                         if (guard >= (1 << 22) && a.d_status)
