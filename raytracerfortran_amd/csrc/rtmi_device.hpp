@@ -602,6 +602,20 @@ __device__ __forceinline__ bool eval_terms(const LayerTable<T> &t, T x, int nful
     T sf = T(0.0), sp = T(0.0);
     bool ok = true;
     int i = 0;
+    if constexpr (!FAST) {
+        // the plain operators are the rare path (operands outside the guards): one term per trip, small code
+#pragma unroll 1
+        for (; i < nfull_wave; ++i) {
+            const LayerPair<T> e = entry(i);
+            const T hv[1] = {e.hv}, vv[1] = {e.vv};
+            add_terms<false, 1>(xx, x, hv, vv, sf, sp);
+        }
+        const T hv[1] = {hvl}, vv[1] = {vvl};
+        add_terms<false, 1>(xx, x, hv, vv, sf, sp);
+        f = R - sf;
+        fp = -sp;
+        return true;
+    }
     for (; i + RTMI_TERM_GROUP - 1 < nfull_wave; i += RTMI_TERM_GROUP) {
         T hv[RTMI_TERM_GROUP], vv[RTMI_TERM_GROUP];
 #pragma unroll
