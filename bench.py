@@ -326,7 +326,7 @@ def main():
                        "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rtmi::fused_kernel<double, false, true, false, false>", "kernel_ms": kern_ms,
+                         "kernel": "rtmi::fused_kernel<double, false, true, false, false, true>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
                          "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; "
                                  "see DESIGN.md section 4"},

@@ -186,7 +186,9 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
 // grid.y = model (many models over one shared source set: loglhood.f90:128-146 per proposal); every
 // workgroup row b of a model owns chunks b, b + gridDim.x, ... of the sources.
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false>
+// ROWS: the launch's layer tables carry one row per stack height (models of up to RTMI_ROWS_MAX_NL interfaces); a
+// template parameter so that each instantiation holds one form of the evaluation loop only (code size).
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
@@ -216,12 +218,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
     T z_next = depth_of(0, wib);
-    const LayerTable<T> t = carve_table(lds, a.nlayers, a.rows != 0);
+    const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS);
     stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
-                                  (RTMI_TABLE_ELEMS(a.nlayers, a.rows != 0) * sizeof(T) + 15) / 16 * 16);  // offset }
+                                  (RTMI_TABLE_ELEMS(a.nlayers, ROWS) * sizeof(T) + 15) / 16 * 16);  // offset }
     T *rz = rR + slots;                                  // depth             } sorted by descending layer
     T *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
@@ -389,10 +391,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
             T f, fp;
-            if (a.rows)
-                eval_f_fp<true>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
-            else
-                eval_f_fp<false>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
             if (live)
                 lane_advance_init(s, f, fp);
             if (valid) {
@@ -742,10 +741,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 dg_terms += (unsigned long long)terms;
                 dg_t0 = clock64();
             }
-            if (a.rows)
-                eval_f_fp<true>(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
-            else
-                eval_f_fp<false>(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
+            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, was_busy, f, fp);
             if (DIAG && fine) {
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
@@ -976,9 +972,13 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
 template <typename T, bool P, bool WT, bool S, bool DIAG = false>
 static hipError_t set_fused_lds_limit()
 {
-    // dynamic LDS above 64 KiB needs the opt-in
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // dynamic LDS above 64 KiB needs the opt-in (both forms of the layer table)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 
 // args: d_vels/d_depths/(d_nlayers|nlayers)/ld_model, sources, outputs, refill_min, tail_group, d_stamps filled by
@@ -1039,16 +1039,24 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
     const bool want_ss = a.d_obs != nullptr;
+#define RTMI_LAUNCH_FUSED(P, WT, S, DG)                                                                          \
+    do {                                                                                                        \
+        if (a.rows)                                                                                             \
+            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, true>), grid, block, lds_bytes, stream, a);       \
+        else                                                                                                    \
+            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, false>), grid, block, lds_bytes, stream, a);      \
+    } while (0)
     if (want_ss && want_t)
-        hipLaunchKernelGGL((fused_kernel<T, false, true, true>), grid, block, lds_bytes, stream, a);
+        RTMI_LAUNCH_FUSED(false, true, true, false);
     else if (want_ss)
-        hipLaunchKernelGGL((fused_kernel<T, false, false, true>), grid, block, lds_bytes, stream, a);
+        RTMI_LAUNCH_FUSED(false, false, true, false);
     else if (want_p)
-        hipLaunchKernelGGL((fused_kernel<T, true, true, false>), grid, block, lds_bytes, stream, a);
+        RTMI_LAUNCH_FUSED(true, true, false, false);
     else if (a.d_stamps)
-        hipLaunchKernelGGL((fused_kernel<T, false, true, false, true>), grid, block, lds_bytes, stream, a);
+        RTMI_LAUNCH_FUSED(false, true, false, true);
     else
-        hipLaunchKernelGGL((fused_kernel<T, false, true, false>), grid, block, lds_bytes, stream, a);
+        RTMI_LAUNCH_FUSED(false, true, false, false);
+#undef RTMI_LAUNCH_FUSED
     return hipGetLastError();
 }
 
