@@ -948,6 +948,17 @@ __device__ __forceinline__ bool travel_time_terms(const LayerTable<T> &t, T p, i
     const T pp = p * p;
     T tt = T(0.0);
     bool ok = true;
+    if constexpr (!(FAST && std::is_same<T, double>::value)) {
+        // the plain operators (rare path in double precision): one layer per trip, small code
+#pragma unroll 1
+        for (int i = 0; i < nfull_wave; ++i) {
+            const int j = i < nfull ? i : t.nul;
+            tt = tt + t.H[j] / (t.V[j] * sqrt(T(1.0) - pp * t.VV[j]));
+        }
+        tt = tt + hl / (t.V[il] * sqrt(T(1.0) - pp * t.VV[il]));
+        tt_out = tt;
+        return true;
+    }
     auto pair = [&](T h0, T v0, T vv0, T h1, T v1, T vv1) {
         const T w0 = T(1.0) - pp * vv0, w1 = T(1.0) - pp * vv1;
         T t0, t1;
