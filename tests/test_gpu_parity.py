@@ -645,6 +645,32 @@ def test_many_layers(rt, O):
         rt.dff(np.ones(1026) * 3000, np.arange(1, 1026.0), 1025, [1.0], [1.0], 1)
 
 
+def test_plain_operators_everywhere(rt, O):
+    """Lengths scaled by 2^110 (2^40 in single precision) put every H, H*V, offset and depth outside the guards of the
+    fast sqrt/divide forms, so every evaluation, start value and travel time of the run goes through the plain
+    operators -- the path a wave otherwise takes only for a stray operand.  Same bits as the oracle on the same
+    scaled inputs, plain and fused kernel, fp64 and fp32."""
+    import torch
+    rng = np.random.default_rng(2468)
+    cases = [c2_workload(120_000, seed=5)]
+    for k in (3, 12, 40):
+        d = np.cumsum(rng.uniform(5.0, 700.0, k - 1))
+        cases.append((rng.uniform(400, 9000, k), d, rng.uniform(0, 2.5 * d[-1], 60_000), rng.uniform(0.5, 1.1 * d[-1], 60_000)))
+    for v, d, off, dep in cases:
+        for dt, scale in ((torch.float64, 2.0 ** 110), (torch.float32, 2.0 ** 40)):
+            ds, offs, deps = d * scale, off * scale, dep * scale
+            want = O.oracle_dff(v, ds, offs, deps) if dt == torch.float64 else O.oracle_dff_f32(v, ds, offs, deps)
+            assert np.isfinite(want[want != -999.0]).all()
+            for path in (1, 2):
+                a = [torch.tensor(x, device="cuda", dtype=dt) for x in (v, ds, offs, deps)]
+                try:
+                    rt.set_option("path", path)
+                    t = rt.trace_device(*a).cpu().numpy()
+                finally:
+                    rt.set_option("path", 0)
+                assert np.array_equal(t, want, equal_nan=True), (path, dt, int((t != want).sum()))
+
+
 def test_unsorted_and_tied_interfaces(rt, O):
     """whichLayer is the reference's scan ("first interface below z"); the kernels search by bisection only when the
     interfaces are in non-decreasing order.  Tied interfaces (zero-thickness layers) keep the bisection, interfaces
