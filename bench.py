@@ -41,17 +41,32 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GH
 BYTES_PER_TT = 24.0
 
 
-def c2_workload(n: int, seed: int = 12345, shard: int = 0):
-    """SURVEY.md 8(d) config C2.  shard > 0 draws a different source set for the same model."""
-    rng = np.random.default_rng(seed)
-    d = np.cumsum(rng.uniform(300, 800, 8))
-    v = np.sort(rng.uniform(1500, 6500, 9))
-    v[[2, 3]] = v[[3, 2]]
-    if shard:
-        rng = np.random.default_rng([seed, shard])
-    off = rng.uniform(10, 8000, n)
-    dep = rng.uniform(50, d[-1] + 500, n)
-    return v, d, off, dep
+from raytracerfortran_amd.synthetic import c2_workload, c4_workload, TRUE_V, TRUE_D  # noqa: E402  (inputs only)
+
+
+def launch_ranks(argv, ngpus: int, backend: str) -> int:
+    """`python bench.py --gpus N` without torchrun: start N fresh child ranks (one per GPU) with
+    `python -m torch.distributed.run` and return its exit code.  Called BEFORE anything in this process touches
+    the GPU (torch.cuda.device_count() does not initialise it on this image); the children are new processes,
+    nothing is re-exec'ed.  RCCL needs one device per rank: fewer visible devices is an error, not a silent
+    1-GPU measurement.  RTMI_BENCH_BACKEND=gloo lets several ranks rehearse the N > 1 path on fewer devices."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < ngpus:
+        print(f"[bench] --gpus {ngpus} but only {ndev} device(s) visible: refusing to measure fewer GPUs than asked "
+              f"(set RTMI_BENCH_BACKEND=gloo to rehearse {ngpus} ranks on {ndev} device(s))", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def host_cores() -> int:
@@ -187,6 +202,51 @@ def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None,
     return elapsed, (kern_ms if kern_ms >= 0 else None)
 
 
+def bench_c4(args, rt, torch, dist, rank, world, dev):
+    """BASELINE config 4's per-GPU share as a driver-runnable number: 32 models drawn from the prior with
+    k in [2, 30] over 1e5 shared sources, one rtmi_trace_batch_device launch with the fused Gaussian logL per step
+    (what one proposal slot of the 256-chain ladder costs each GPU; travel times are not materialised, as in the
+    sampler).  Models differ per rank (seed + rank), sources are replicated: chains shard, no collective."""
+    nsrc = 100_000 if args.nsrc == 1_000_000 else args.nsrc
+    nm = 32
+    w = c4_workload(nm, nsrc, seed=404 + 1000 * rank)
+    f64 = torch.float64
+    t = lambda a: torch.tensor(a, device=dev)
+    dV, dD, dNL, do, dz, dsd = t(w["V"]), t(w["D"]), t(w["NL"]), t(w["off"]), t(w["dep"]), t(w["sd"])
+    true_t = rt.trace_device(torch.tensor(TRUE_V, device=dev, dtype=f64), torch.tensor(TRUE_D, device=dev, dtype=f64), do, dz)
+    dobs = true_t + t(w["obs_noise"])
+    stream = torch.cuda.current_stream()
+    out = {}
+
+    def step():
+        out["L"] = rt.trace_batch_device(dV, dD, dNL, do, dz, obs=dobs, sd=dsd, want_timeP=False, stream=stream)[1]
+
+    elapsed, kern_ms = timed_steps(step, args.steps, args.warmup, world, dist if world > 1 else None, dev,
+                                   sync=torch.cuda.synchronize,
+                                   make_event=lambda: torch.cuda.Event(enable_timing=True), stream=stream)
+    if rank == 0:
+        value = world * nm * nsrc * args.steps / elapsed
+        algo = 16.0 * nm * nsrc + 8.0 * nm   # SURVEY.md 8(d): shared sources re-read per model, one logL per model
+        achieved = algo / (kern_ms * 1e-3) / 1e9
+        res = {"metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "ranks": world, "devices": args.devices, "collective_backend": args.backend,
+               "config": {"workload": "C4 per-GPU share: 32 models (prior draws, k in [2,30]) x %d shared sources, travel "
+                                      "times + fused logL in one launch; BASELINE.json configs[3]" % nsrc,
+                          "models_per_gpu": nm, "nsrc": nsrc, "k_range": [int(w["NL"].min()) + 1, int(w["NL"].max()) + 1],
+                          "sharding": "chains (models) per rank, sources replicated, no collective in the step"},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                            "kernel": "rtmi::fused_kernel<double, false, false, true, false, false> + loglike_kernel",
+                            "algorithmic_bytes_per_launch": algo,
+                            "note": "fp64-VALU-bound root-find (DESIGN.md section 4)"},
+               "logL_finite": bool(torch.isfinite(out["L"]).all().item())}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_pt(args, rt, torch, dist, rank, world, dev):
     """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, native sweep csrc/rtmi_pt.cpp): 32 chains per GPU over 1e4 shared sources
     (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
@@ -234,6 +294,7 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
         res = {"metric": "travel-times/sec", "value": models * nsrc / elapsed, "unit": "travel-times/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "ranks": world, "devices": args.devices, "collective_backend": args.backend,
                "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,10], "
                                       "swap round every sweep (BASELINE configs 3/4 shape)" % nsrc,
                           "chains": nloc * world, "models_evaluated": models,
@@ -244,22 +305,32 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nsrc", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive drop-in figures (c2 only)")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
-    ap.add_argument("--workload", choices=["c2", "pt"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "pt", "c4"], default="c2",
                     help="c2: single dff forward, 1e6 sources (the bench metric's configuration, default); "
-                         "pt: parallel-tempering sweeps, 32 chains per GPU x 1e4 sources (BASELINE configs 3/4 shape)")
+                         "pt: parallel-tempering sweeps, 32 chains per GPU x 1e4 sources (BASELINE config 3 shape); "
+                         "c4: batched likelihood of config 4's per-GPU share, 32 models (k in [2,30]) x 1e5 sources")
     ap.add_argument("--path", choices=["auto", "plain", "fused"], default="auto",
                     help="kernel path of rtmi_trace_device (A/B runs; auto = what the library picks)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
     if args.path != "auto":
         os.environ["RTMI_FORCE_PATH"] = args.path  # read once by librtmi.so
+    backend = os.environ.get("RTMI_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks; this process never touches the GPU
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus, backend))
 
     import torch
     import torch.distributed as dist
@@ -267,21 +338,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"[bench] {world} ranks but {ndev} device(s): RCCL needs one device per rank")
+    local_rank = local_rank % max(1, ndev)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL by default; RTMI_BENCH_BACKEND=gloo lets several ranks rehearse the N > 1 path on ONE GPU
-        backend = os.environ.get("RTMI_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+    args.devices = min(world, ndev)
+    args.backend = ("rccl" if backend == "nccl" else backend) if world > 1 else None
 
     import raytracerfortran_amd as rt
     rt.load_library()
@@ -289,6 +365,8 @@ def main():
 
     if args.workload == "pt":
         return bench_pt(args, rt, torch, dist, rank, world, dev)
+    if args.workload == "c4":
+        return bench_c4(args, rt, torch, dist, rank, world, dev)
 
     n = args.nsrc
     v, d, off, dep = c2_workload(n, shard=rank)
@@ -320,7 +398,7 @@ def main():
             "metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic", "ranks": world, "devices": args.devices, "collective_backend": args.backend,
             "config": {"workload": "C2: single dff forward, 1e6 sources x 8 interfaces (9 velocities, one LVZ), "
                                    "seed 12345; BASELINE.json configs[1]",
                        "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},

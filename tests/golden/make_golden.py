@@ -20,6 +20,8 @@ Fixtures
   ref_batches.npz   seeded synthetic models x sources with the travel times the
                     compiled reference returns for them (flang -O2; the -O0
                     build's max deviation is recorded in the index).
+  c4_models.npz     BASELINE config 4 at its full source count: the k = 30 and k = 2 models of the seeded C4
+                    workload x 1e5 shared sources (sources regenerated from the recipe; digest stored).
   index.json        per-case metadata (seed, sizes, what the case exercises,
                     reference branch statistics from the oracle's counters).
 """
@@ -167,8 +169,29 @@ def synth_cases():
     return cases
 
 
+def c4_fixture():
+    """BASELINE config 4 at full source count: the k = 30 and the k = 2 model of the seeded C4 workload
+    (raytracerfortran_amd/synthetic.py) over all 1e5 shared sources, travel times from the compiled reference.
+    The sources are regenerated from the recipe by the tests (their SHA-256 is stored), so the file holds the two
+    models and 2 x 1e5 reference times only."""
+    from raytracerfortran_amd import synthetic as S
+    w = S.c4_workload(32)
+    out = {"digest_sources": np.frombuffer(bytes.fromhex(S.digest(w["off"], w["dep"])), dtype=np.uint8)}
+    for name, m in (("k30", 0), ("k2", 1)):
+        nl = int(w["NL"][m])
+        v, d = w["V"][m, :nl + 1], w["D"][m, :nl]
+        t = O.ref_dff(v, d, w["off"], w["dep"])
+        t0 = O.ref_dff(v, d, w["off"], w["dep"], opt="O0")
+        both = (t != -999.0) & (t0 != -999.0)
+        print(f"c4 {name}: nl={nl} sentinels={int((t == -999.0).sum())} O0-vs-O2 max {np.abs(t - t0)[both].max():.3e}")
+        out[f"{name}__vels"], out[f"{name}__depths"], out[f"{name}__timeP"] = v, d, t
+    np.savez_compressed(os.path.join(HERE, "c4_models.npz"), **out)
+
+
 def main():
     assert O.have_ref(), "run `make -C oracle ref` first (needs /root/reference and amdflang)"
+    if "--c4-only" in sys.argv:
+        return c4_fixture()
     kat = author_kats()
     with open(os.path.join(HERE, "kat_author.json"), "w") as f:
         json.dump(kat, f, indent=1)
@@ -196,6 +219,7 @@ def main():
                    "cases": index}, f, indent=1)
     tot = sum(c["nsrc"] for c in index)
     print(f"wrote {len(index)} cases, {tot} sources")
+    c4_fixture()
 
 
 if __name__ == "__main__":

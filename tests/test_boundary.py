@@ -157,3 +157,47 @@ def test_bench_timing_harness_two_ranks_gloo():
     assert k0 is None and c0 == c1 == 12  # exactly warmup + steps calls
     assert samev0 and samev1               # one model on every rank
     assert sameoff0 and not sameoff1       # a different source shard on rank 1
+
+
+def test_bench_gpus_n_self_launches_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` without torchrun becomes the launcher of N fresh ranks (never a 1-rank measurement
+    labelled N): the command it builds, and its refusal when RCCL is asked for more ranks than devices."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert bench.launch_ranks(["--gpus", "4", "--steps", "7"], 4, "nccl") == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # fewer devices than ranks: RCCL refuses (exit code 2, nothing launched), gloo rehearsal is allowed
+    seen.clear()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.launch_ranks(["--gpus", "4"], 4, "nccl") == 2 and not seen
+    assert bench.launch_ranks(["--gpus", "2"], 2, "gloo") == 0 and "--nproc-per-node=2" in seen["cmd"]
+
+
+def test_bench_gpus_n_exits_nonzero_without_devices():
+    """End to end on this CPU container: `python bench.py --gpus 2` must fail loudly, not print a 1-GPU line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTMI_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 2 and "refusing to measure fewer GPUs" in p.stderr and not p.stdout.strip()
+    # under a launcher with the wrong world size it refuses as well
+    env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=3 but --gpus 2" in p.stderr

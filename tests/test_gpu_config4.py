@@ -1,0 +1,121 @@
+"""BASELINE config 4 on one GPU: 32 (the per-GPU share) and 256 (the whole job) models drawn from the sampler's
+prior with k in [2, 30] over 1e5 shared sources, travel times + fused Gaussian logL, both kernel paths.
+
+What the reference computes here: one `CALL TraceRays` per model from LOGLHOOD_RT (loglhood.f90:128-146) followed by
+the residual sum and logL (:165-199), for every chain of the tempering ladder (prjmh_temper_rf.f90:116-135).
+Bar: travel times BIT-EQUAL to the oracle (and to the compiled reference for the committed k = 30 / k = 2 models),
+logL within 1e-11 relative.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import compare_times
+from test_oracle_golden import c4_fixture
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+NSRC = 100_000
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracerfortran_amd as r
+    r.load_library()
+    r.init(0)
+    return r
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def oracle_batch(O, w, models):
+    """Oracle travel times of the given models over the shared sources; threads over models (the C code holds no
+    shared state and ctypes releases the GIL)."""
+    def one(m):
+        nl = int(w["NL"][m])
+        return O.oracle_dff(w["V"][m, :nl + 1], w["D"][m, :nl], w["off"], w["dep"])
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        return dict(zip(models, ex.map(one, models)))
+
+
+def c4_inputs(O, nmodels):
+    from raytracerfortran_amd import synthetic as S
+    w = S.c4_workload(nmodels, NSRC)
+    w["obs"] = O.oracle_dff(S.TRUE_V, S.TRUE_D, w["off"], w["dep"]) + w["obs_noise"]
+    return w
+
+
+def run_batch(rt, w, path, want_timeP=True):
+    import torch
+    dev = "cuda"
+    a = [torch.tensor(w[k], device=dev) for k in ("V", "D", "NL", "off", "dep")]
+    try:
+        rt.set_option("path", path)
+        T, L = rt.trace_batch_device(*a, obs=torch.tensor(w["obs"], device=dev), sd=torch.tensor(w["sd"], device=dev),
+                                     want_timeP=want_timeP)
+        torch.cuda.synchronize()
+    finally:
+        rt.set_option("path", 0)
+    assert rt.load_library().rtmi_device_status() == 0
+    return (T.cpu().numpy() if T is not None else None), L.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_config4_per_gpu_share_32_models(rt, O, path):
+    """32 models x 1e5 sources (what one of the 8 GPUs holds): every travel time against the oracle."""
+    w = c4_inputs(O, 32)
+    assert w["NL"].min() == 1 and w["NL"].max() == 29
+    T, L = run_batch(rt, w, path)
+    ref = oracle_batch(O, w, range(32))
+    for m in range(32):
+        assert compare_times(T[m], ref[m], TOL) == 0.0, f"model {m} (k={w['NL'][m] + 1}) not bit-identical"
+        ll = O.oracle_loglhood_rt(w["obs"], ref[m], w["sd"][m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+    # the two committed models of this workload against the compiled reference itself
+    z, _ = c4_fixture()
+    assert compare_times(T[0], z["k30__timeP"], TOL) == 0.0
+    assert compare_times(T[1], z["k2__timeP"], TOL) == 0.0
+    # logL alone (no travel times materialised) is the same number
+    _, L2 = run_batch(rt, w, path, want_timeP=False)
+    assert np.array_equal(L, L2)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_config4_whole_job_256_models(rt, O, path):
+    """256 models x 1e5 sources in one launch (the whole ladder of config 4 on one GPU, timeP = 205 MB): travel times
+    of a fixed subset of models (every 8th, plus the k = 30 and k = 2 ones) bit-equal to the oracle, logL of those
+    within 1e-11; the remaining models are checked through the logL identity between the two kernel paths below."""
+    w = c4_inputs(O, 256)
+    T, L = run_batch(rt, w, path)
+    subset = sorted(set(range(0, 256, 8)) | {0, 1} | {int(np.argmax(w["NL"])), int(np.argmin(w["NL"]))})
+    ref = oracle_batch(O, w, subset)
+    for m in subset:
+        assert compare_times(T[m], ref[m], TOL) == 0.0, f"model {m} (k={w['NL'][m] + 1}) not bit-identical"
+        ll = O.oracle_loglhood_rt(w["obs"], ref[m], w["sd"][m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+    # every model: sentinel count sane, residual-based logL finite, and the travel times of ALL 256 models are the
+    # same bits through the other kernel path (size-independent property: the two kernels share only the arithmetic)
+    T2, L2 = run_batch(rt, w, 3 - path)
+    assert np.array_equal(T, T2)
+    assert np.all(np.isfinite(L)) and np.allclose(L, L2, rtol=1e-11, atol=0)
+
+
+def test_config4_host_entry_points(rt, O):
+    """The same 32 x 1e5 batch through READDATA + LOGLHOOD as the sampler calls them: rtmi_set_sources once, then
+    rtmi_loglhood_batch (host arrays)."""
+    w = c4_inputs(O, 32)
+    rt.set_sources(w["off"], w["dep"], w["obs"])
+    L, SS = rt.loglhood_batch(w["V"], w["D"], w["NL"], w["sd"], want_ss=True)
+    ref = oracle_batch(O, w, range(32))
+    for m in range(32):
+        ll = O.oracle_loglhood_rt(w["obs"], ref[m], w["sd"][m], stable=True)
+        assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
+        ss = float(np.sum((w["obs"] - ref[m]) ** 2))
+        assert abs(SS[m] - ss) <= 1e-10 * ss

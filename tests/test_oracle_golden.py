@@ -137,3 +137,23 @@ def test_fp32_oracle_tracks_fp64():
     both = (t32 != -999.0) & (t64 != -999.0)
     dt = np.abs(t32[both].astype(np.float64) - t64[both])
     assert both.mean() > 0.99 and np.median(dt) < 1e-5
+
+
+def c4_fixture():
+    """tests/golden/c4_models.npz + the seeded C4 workload it was generated from (digest-checked)."""
+    import os
+    from conftest import GOLDEN
+    from raytracerfortran_amd import synthetic as S
+    z = np.load(os.path.join(GOLDEN, "c4_models.npz"), allow_pickle=False)
+    w = S.c4_workload(32)
+    assert bytes(z["digest_sources"]).hex() == S.digest(w["off"], w["dep"]), "C4 source recipe drifted from the fixture"
+    return z, w
+
+
+@pytest.mark.parametrize("name", ["k30", "k2"])
+def test_config4_full_size_fixture(name):
+    """BASELINE config 4's source count (1e5) on its largest (k = 30) and smallest (k = 2) model: the oracle against
+    travel times of the compiled reference."""
+    z, w = c4_fixture()
+    t = O.oracle_dff(z[f"{name}__vels"], z[f"{name}__depths"], w["off"], w["dep"])
+    assert compare_times(t, z[f"{name}__timeP"], tol=1e-12) == 0.0
