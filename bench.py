@@ -164,18 +164,69 @@ def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
     return out
 
 
-def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None, stream=None):
+def dropin_figures(rt, v, d, off, dep, ref_t=None):
+    """PCIe-inclusive cost of the drop-in symbol itself: `dff_` called through the C ABI on pageable host arrays, the
+    way R's .Fortran or a Fortran caller does (no Python-side copies: the arrays are allocated once, ctypes passes
+    their addresses).  Reported next to the device-resident headline, never as `value`."""
+    import ctypes
+    lib = rt.load_library()
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+
+    def caller(nl, off_a, dep_a):
+        n = off_a.size
+        t = np.zeros(n)
+        cn, cl, kd = ctypes.c_int(n), ctypes.c_int(nl), ctypes.c_int(-1)
+        a = (v.ctypes.data_as(dp), d.ctypes.data_as(dp), ctypes.byref(cl), off_a.ctypes.data_as(dp),
+             dep_a.ctypes.data_as(dp), ctypes.byref(cn), t.ctypes.data_as(dp), ctypes.byref(kd))
+        return (lambda: lib.dff_(*a)), t
+
+    def median_ms(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, float(np.min(ts)) * 1e3
+
+    out = {}
+    n = off.size
+    big, t_big = caller(d.size, off, dep)
+    med, best = median_ms(big, 15, 3)
+    out["dff_1e6_ms" if n == 1_000_000 else f"dff_{n}_ms"] = med
+    out["dff_large_best_ms"] = best
+    out["dff_large_travel_times_per_s"] = n / (med * 1e-3)
+    out["pcie_floor_ms"] = 24.0 * n / 63e9 * 1e3
+    if ref_t is not None:
+        out["dff_large_bit_equal_to_device_path"] = bool(np.array_equal(t_big, ref_t))
+    small, _ = caller(d.size, np.ascontiguousarray(off[:20]), np.ascontiguousarray(dep[:20]))
+    med20, best20 = median_ms(small, 300, 20)
+    out["dff_nsrc20_us"] = med20 * 1e3
+    out["dff_nsrc20_best_us"] = best20 * 1e3
+    out["devices"] = os.environ.get("RTMI_DEVICES", "bound device only")
+    out["note"] = ("host buffers in, host buffers out through the C symbol dff_ (pageable memory, PCIe inclusive); "
+                   "median of 15 calls at the bench size, of 300 calls at the reference's example size NSrc = 20")
+    return out
+
+
+def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None, stream=None, run_steps=None):
     """The timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a
     device synchronise on both sides; returns (max-over-ranks wall seconds, max-over-ranks average
     per-launch milliseconds from HIP events recorded on the launch stream, or None without events).
-    `dist` is torch.distributed (initialised) or None; works with gloo on CPU for the tests."""
+    `dist` is torch.distributed (initialised) or None; works with gloo on CPU for the tests.
+    `run_steps(n)`, when given, enqueues n steps in one call (a device-resident loop) instead of n calls of `step`."""
     import torch
 
     def barrier():
         if dist is not None and world > 1:
             dist.barrier()
 
-    for _ in range(warmup):
+    if run_steps is not None:
+        if warmup:
+            run_steps(warmup)
+        step = None
+    for _ in range(warmup if step is not None else 0):
         step()
     sync()
     barrier()
@@ -186,8 +237,11 @@ def timed_steps(step, steps, warmup, world, dist, device, sync, make_event=None,
     t0 = time.perf_counter()
     if ev0 is not None:
         ev0.record(stream)
-    for _ in range(steps):
-        step()
+    if run_steps is not None:
+        run_steps(steps)
+    else:
+        for _ in range(steps):
+            step()
     if ev1 is not None:
         ev1.record(stream)
     sync()
@@ -248,7 +302,7 @@ def bench_c4(args, rt, torch, dist, rank, world, dev):
 
 
 def bench_pt(args, rt, torch, dist, rank, world, dev):
-    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, native sweep csrc/rtmi_pt.cpp): 32 chains per GPU over 1e4 shared sources
+    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, device-resident sweep csrc/rtmi_pt.hip): 32 chains per GPU over 1e4 shared sources
     (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
     logL all-gather over RCCL.  A "step" is one sweep of every chain; value = travel times traced per second."""
     from raytracerfortran_amd import tempering as T
@@ -269,22 +323,27 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                   dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)
 
-    def step():
-        s.sweep()
-        if world > 1 or nloc > 1:
-            s.swap_round()
+    device_loop = world == 1 or s.comm is not None
+    if device_loop:
+        # sweeps + swap rounds enqueued back to back by ONE library call per timed region: no host synchronisation
+        # between the first launch and the last (rtmi_pt_run); the exchange is the library's RCCL all-gather
+        def run_steps(n):
+            s.native.run(n, 1, s.comm, 0)
+    else:
+        # rehearsal of N ranks without RCCL (gloo): the gather of every swap round goes through the host
+        def run_steps(n):
+            for _ in range(n):
+                s.sweep()
+                s.swap_round()
 
-    m0 = [0]
-
-    def timed_step():
-        step()
-
-    for _ in range(args.warmup):
-        step()
-    m0[0] = ev.models
-    elapsed, _ = timed_steps(timed_step, args.steps, 0, world, dist if world > 1 else None, dev,
-                             sync=torch.cuda.synchronize)
-    models = ev.models - m0[0]
+    run_steps(args.warmup)
+    st0 = s.native.stats()
+    elapsed, _ = timed_steps(None, args.steps, 0, world, dist if world > 1 else None, dev,
+                             sync=torch.cuda.synchronize, run_steps=run_steps)
+    st1 = s.native.stats()
+    models = st1["models"] - st0["models"]
+    launches = st1["launches"] - st0["launches"]
+    s.sync()
     if world > 1:
         tm = torch.tensor([float(models)], dtype=torch.float64,
                           device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -298,7 +357,9 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,10], "
                                       "swap round every sweep (BASELINE configs 3/4 shape)" % nsrc,
                           "chains": nloc * world, "models_evaluated": models,
-                          "launches_per_step": ev.launches / max(1, args.steps + args.warmup),
+                          "launches_per_step": launches / max(1, args.steps),
+                          "engine": "device-resident sweep (rtmi_pt_run), swap exchange: "
+                                    + ("RCCL all-gather" if s.comm is not None else ("local" if world == 1 else "host gather (gloo rehearsal)")),
                           "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"])}}
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -430,6 +491,8 @@ def main():
             res["valu_fp64"]["source"] = mc[2]
         if check is not None:
             res["check_vs_oracle"] = check
+        if world == 1 and not args.no_dropin:
+            res["dropin"] = dropin_figures(rt, v, d, off, dep, dt.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(v, d, off, dep)
         print(json.dumps(res), flush=True)

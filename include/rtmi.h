@@ -87,24 +87,31 @@ void rtmi_dff7(const double *vels, const double *depths, const int *NLayers, dou
  * The k = 1 model is passed the way LOGLHOOD_RT does: nlayers = 1, vels = (v, v), depths = (9999.9).
  */
 int rtmi_set_sources(const double *src_offset, const double *src_depth, const double *obs, int64_t nsrc);
+/* Identifies the resident source set: bumped by every rtmi_set_sources (0 = none yet).  The set is ONE per process
+ * (READDATA's data are module variables in the reference as well); a caller that caches anything derived from it can
+ * detect that somebody else replaced it.  rtmi_pt handles do not depend on it after creation: they keep their own copy. */
+uint64_t rtmi_sources_generation(void);
 int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t *nlayers, int ld_model,
                         int nmodels, const double *sd, double *logL, double *ss);
 
 /*
- * Native Metropolis-Hastings sweep of the reversible-jump sampler over the resident sources
- * (rtmi_set_sources with observations first).  One handle = the tempered chains of one process; every
- * proposal slot of a sweep -- birth/death, then each (node, parameter) perturbation -- is ONE
- * rtmi_loglhood_batch launch for all chains, decisions are taken on the host:
+ * The Metropolis-Hastings sweep of the reversible-jump tempering sampler, RESIDENT ON THE GPU (csrc/rtmi_pt.hip).
+ * One handle = the tempered chains of one process (one GPU).  Chain state -- k nodes (depth, Vp), node 1 the surface
+ * node whose depth is not perturbed, sigma, logL, SS, beta, the position of the chain's counter-based random stream --
+ * lives in HBM; every proposal slot of a sweep (birth/death, then each (node, parameter) perturbation) is one small
+ * kernel (decide the previous slot, propose the next) plus ONE batched likelihood launch for all chains over the
+ * handle's source set; nothing of a sweep runs on the host and a sweep is replayed as a captured hipGraph:
  *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
  *   EXPLORE_MH           prjmh_temper_rf.f90:521-634   PROPOSAL_SDRT :1616   CHECKBOUNDS :1639
- * for the reference configuration NPL = 2, ENOS = 0, IPOIPR = 1, ICOV = 1, I_VARPAR = 0.  Chain state: k
- * nodes (depth, Vp), node 1 the surface node whose depth is not perturbed, and sigma.  The temperature
- * exchange (TEMPSWP_MH :1329) is left to the caller, which owns the collective: it reads logL with
- * rtmi_pt_get_chain and writes the new temperatures with rtmi_pt_set_beta.
+ *   TEMPSWP_MH           prjmh_temper_rf.f90:1329-1357 (replaces the pairing through rank 0, :331-349)
+ * for the reference configuration NPL = 2, ENOS = 0, IPOIPR = 1, ICOV = 1, I_VARPAR = 0.  Chain-level parity with the
+ * reference is statistical (its RANDOM_NUMBER streams are compiler specific); every logL the sampler acts on is the
+ * bit-exact forward model.
  */
 typedef struct rtmi_pt rtmi_pt;
+typedef struct rtmi_comm rtmi_comm;
 typedef struct {
-    int kmin, kmax;          /* NLMN, NLMX                                  read_input.f90:39-40  */
+    int kmin, kmax;          /* NLMN, NLMX (kmax <= 64)                     read_input.f90:39-40  */
     double lambda;           /* Poisson prior on k                          read_input.f90:78-81  */
     double hmx, hmin;        /* max partition depth, min layer thickness    read_input.f90:46-47  */
     double vmin, vmax;       /* Vp bounds (1500, 10000)                     read_input.f90:207-208 */
@@ -112,8 +119,10 @@ typedef struct {
     double pertsdsc;         /* Cauchy step = (max - min) / pertsdsc (30)   read_input.f90:169,214 */
     double pertsdsdsc;       /* sigma step = (sdmax - sdmin) / this (10)    read_input.f90:237-239 */
 } rtmi_pt_prior;
-/* ld_model >= kmax + 1; ndata = number of observations of the resident source set; (seed, stream_id)
- * select the random streams (one per chain; use the rank as stream_id).  NULL on bad arguments. */
+/* Creates the chains over the source set currently resident (rtmi_set_sources with observations first): the handle
+ * takes its OWN device copy of that set, so a later rtmi_set_sources -- or a second handle over other data -- does
+ * not retarget it.  ndata must equal the resident set's size; ld_model >= kmax + 1; (seed, stream_id, chain) select
+ * the random streams (use the rank as stream_id).  NULL on bad arguments (text in rtmi_last_error). */
 rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_prior *prior, uint64_t seed,
                         uint64_t stream_id);
 void rtmi_pt_destroy(rtmi_pt *h);
@@ -122,10 +131,56 @@ int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const 
 int rtmi_pt_set_beta(rtmi_pt *h, const double *beta);
 int rtmi_pt_get_chain(const rtmi_pt *h, int chain, int *k, double *depths, double *vels, double *sd,
                       double *logL, double *ss);
+/* every chain in one read-back: k[nchains], depths/vels[nchains][kmax], sd/logL/ss/beta[nchains]; any may be NULL */
+int rtmi_pt_get_all(rtmi_pt *h, int *k, double *depths, double *vels, double *sd, double *logL, double *ss,
+                    double *beta);
 int rtmi_pt_evaluate(rtmi_pt *h);             /* logL of the current states (after set_chain) */
-int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* nsweeps x (EXPLORE_MH_NOVARPAR + EXPLORE_MH) for every chain */
-/* out8: accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, launches, models */
+int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* = rtmi_pt_run(h, nsweeps, 0, NULL, 0) */
+/* out8: accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, likelihood launches,
+ * models evaluated */
 int rtmi_pt_stats(const rtmi_pt *h, int64_t *out8);
+
+/*
+ * Temperature ladder and exchange.  level[c] = temperature level of GLOBAL chain c (replicated on every rank),
+ * beta = beta_of_level[level]; this handle holds global chains first_chain .. first_chain + nchains - 1.
+ *   rtmi_pt_swap_round       one exchange: all-gather of the local logL over `comm` (RCCL; NULL when every chain is
+ *                            local), then the deterministic adjacent-level pairing + Metropolis rule on the device,
+ *                            identical on every rank, swapping LEVELS (temperatures) in place -- no model state moves.
+ *                            Message size: 8 B per chain per round (256 chains: 2 KB).  Asynchronous on the handle's stream.
+ *   rtmi_pt_swap_round_host  the same with the gather done by the caller (MPI_Allgather, gloo ...): logl_all[nchains_total].
+ *   rtmi_pt_swap_decide      the pairing + acceptance rule alone, on the host, no GPU: what the device runs.
+ *   rtmi_pt_run              nsweeps sweeps; a swap round after every swap_every-th sweep (0 = never); the chains at
+ *                            T = 1 appended to the sample ring after every record_every-th sweep of this call (0 = never).  The
+ *                            whole run is enqueued without host synchronisation; the call returns after ONE synchronise.
+ */
+int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int *level, const double *beta_of_level,
+                       int nlevels);
+int rtmi_pt_get_ladder(rtmi_pt *h, int *level, int64_t *swap_stats2 /* accepted, proposed */);
+int rtmi_pt_swap_round(rtmi_pt *h, rtmi_comm *comm);
+int rtmi_pt_swap_round_host(rtmi_pt *h, const double *logl_all);
+int rtmi_pt_swap_decide(int nchains_total, const double *logl_all, int *level, const double *beta_of_level, int nlevels,
+                        uint64_t seed, uint64_t round, int64_t *proposed);
+int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int record_every);
+/* sample ring of the T = 1 chains (device memory, `capacity` samples; 0 frees it) and its read-out: returns the number
+ * of samples copied (<= max_samples) and empties the ring; depths/vels are [max_samples][kmax]; *dropped = samples
+ * that did not fit since the last read-out.  Negative = -status. */
+int rtmi_pt_sample_buffer(rtmi_pt *h, int capacity);
+int rtmi_pt_samples(rtmi_pt *h, int max_samples, int64_t *sweep, int *chain, int *k, double *sd, double *logL,
+                    double *depths, double *vels, int *dropped);
+
+/*
+ * The communicator of the exchange: RCCL over xGMI, one rank per GPU (the bound device of rtmi_init).  Rank 0 makes
+ * the id, the host program broadcasts its RTMI_COMM_ID_BYTES bytes (MPI_Bcast in the reference's world), every rank
+ * calls rtmi_comm_create.  Replaces the MPI_SEND/MPI_RECV pairs of prjmh_temper_rf.f90:331-349.
+ */
+#define RTMI_COMM_ID_BYTES 128
+int rtmi_comm_unique_id(char id[RTMI_COMM_ID_BYTES]);
+rtmi_comm *rtmi_comm_create(int nranks, int rank, const char id[RTMI_COMM_ID_BYTES]);
+void rtmi_comm_destroy(rtmi_comm *comm);
+int rtmi_comm_size(const rtmi_comm *comm);
+int rtmi_comm_rank(const rtmi_comm *comm);
+/* all-gather of `count` doubles per rank, device pointers, asynchronous on `stream` */
+int rtmi_comm_allgather_f64(rtmi_comm *comm, const double *d_send, double *d_recv, int64_t count, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Library state.
@@ -137,12 +192,16 @@ int rtmi_init(int device);
 const char *rtmi_last_error(void);
 int rtmi_version(void);
 /*
- * Sticky fault word of the device code: 0, or a bit mask if a kernel ever ran out of one of its bounded waits (the
- * hand-over ring of the fused kernel is deadlock-free by construction; the bounds exist so that a fault could never
- * hang the GPU).  The host-pointer entry points check it after their synchronise and fail; callers of the
- * asynchronous device entry points can poll it after their own synchronise.
+ * Sticky fault word of the device code: 0, or a bit mask: bits 1, 2, 4 = a kernel ran out of one of its bounded waits
+ * (the hand-over ring of the fused kernel is deadlock-free by construction; the bounds exist so that a fault could never
+ * hang the GPU); bit 8 = a row of rtmi_trace_batch_device had d_nlayers outside [1, ld_model - 1].  The host-pointer
+ * entry points check it after their synchronise and fail; callers of the asynchronous device entry points can poll it
+ * after their own synchronise.  The word is allocated by rtmi_init or by the first un-captured call of any entry
+ * point; a FIRST call made inside a stream capture is refused with RTMI_ERR_BAD_ARG (call rtmi_init before capturing).
  */
 int rtmi_device_status(void);
+/* Resets the fault word (after the caller has dealt with what it reported); returns the value it had. */
+int rtmi_clear_device_status(void);
 /* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
 int rtmi_device_cus(void);
 /*
@@ -202,7 +261,8 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
  * TraceRays from LOGLHOOD_RT compute (loglhood.f90:128-146), in one launch.
  *   d_vels   [nmodels][ld_model]   row m holds nlayers[m]+1 velocities
  *   d_depths [nmodels][ld_model]   row m holds nlayers[m] interface depths
- *   d_nlayers[nmodels]             int32, each in [1, RTMI_MAX_LAYERS]
+ *   d_nlayers[nmodels]             int32, each in [1, ld_model - 1]; the kernels check it: a row outside that range
+ *                                  gets NaN travel times / NaN logL and sets bit 8 of rtmi_device_status()
  *   d_timeP  [nmodels][nsrc]       may be NULL when only logL is wanted
  * Optional fused Gaussian log-likelihood (loglhood.f90:165-199, ICOV = 1, one mode):
  *   d_obs[nsrc], d_sd[nmodels] -> d_logL[nmodels]; pass NULL for all three to skip.

@@ -17,15 +17,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtmi.so")
 LIB7 = os.path.join(HERE, "librtmi_dff7.so")
-SOURCES = [os.path.join(CSRC, "rtmi_kernels.hip"), os.path.join(CSRC, "rtmi_capi.cpp"),
-           os.path.join(CSRC, "rtmi_pt.cpp")]
+SOURCES = [os.path.join(CSRC, f) for f in ("rtmi_kernels.hip", "rtmi_capi.cpp", "rtmi_pt.hip", "rtmi_comm.cpp")]
 SHIM7 = os.path.join(CSRC, "rtmi_dff7_shim.c")
-HEADERS = [os.path.join(CSRC, "rtmi_kernels.h"), os.path.join(CSRC, "rtmi_device.hpp"), os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("rtmi_kernels.h", "rtmi_device.hpp", "rtmi_host.h", "rtmi_pt_rules.h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17",
-         f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
+OBJDIR = os.path.join(CSRC, "build")
+CFLAGS = ["-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall",
+          "-Wno-unused-result"]
+LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}"]
+ROCM_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
+LIBS = [f"-L{ROCM_LIB}", "-lrccl", "-lpthread"]
 
 
 def _stale(target: str, deps) -> bool:
@@ -36,11 +40,25 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    deps = SOURCES + HEADERS + [os.path.abspath(__file__)]
-    if force or _stale(LIB, deps):
-        if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
-            raise RuntimeError("hipcc not found: librtmi.so cannot be built and there is no CPU fallback")
-        cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
+    """One object per source under csrc/build/ (so that touching the host code does not recompile the kernels), then
+    the link.  librccl carries the temperature-swap exchange of the tempering entry points (csrc/rtmi_comm.cpp)."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        if os.path.exists(LIB) and not force:
+            return LIB
+        raise RuntimeError("hipcc not found: librtmi.so cannot be built and there is no CPU fallback")
+    objs, relink = [], force or not os.path.exists(LIB)
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [HIPCC] + CFLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or _stale(LIB, objs):
+        cmd = [HIPCC] + LDFLAGS + ["-o", LIB] + objs + LIBS
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

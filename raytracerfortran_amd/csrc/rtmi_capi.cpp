@@ -7,21 +7,23 @@
 // if the GPU path cannot run, the call fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
-#include "../../include/rtmi.h"
-#include "rtmi_kernels.h"
+#include "rtmi_host.h"
 
-namespace {
+namespace rtmi_host {
 
-thread_local std::string g_err;
+static thread_local std::string g_err;
 
 int fail(int code, const char *fmt, ...)
 {
@@ -34,52 +36,13 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(RTMI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
-    } while (0)
-
-#define RTMI_SMALL_CALL_NSRC 4096  // dff_ / TraceRays calls up to this size run on a mapped pinned buffer
-
-// Per-process context of the host-pointer entry points.
-struct Context {
-    std::mutex mu;
-    bool ready = false;
-    int device = 0;
-    int cus = 0;
-    hipStream_t stream = nullptr;
-    // grow-only device buffers of the drop-in path
-    double *d_model = nullptr;  // vels | depths
-    size_t model_cap = 0;
-    double *d_src = nullptr;    // offset | depth | timeP | p_final
-    size_t src_cap = 0;
-    // resident source set of the likelihood entry points (rtmi_set_sources)
-    double *d_set = nullptr;    // offset | depth | obs
-    size_t set_cap = 0;
-    int64_t set_n = 0;
-    bool set_has_obs = false;
-    double *d_lk = nullptr;     // models | sd | logL | ss | partial sums
-    size_t lk_cap = 0;
-    double *h_pin = nullptr;    // pinned staging of one batch (models in, logL/ss out)
-    size_t pin_cap = 0;
-    double *h_small = nullptr;  // pinned, device-mapped buffer of the small-call path of dff_ / TraceRays
-    size_t small_cap = 0;
-};
-
-// Sticky fault word of the fused kernel: pinned host memory mapped into the device (written by a kernel only if one
-// of its bounded waits runs out; read by the host for free).  Allocated once per process, by the first caller.
-struct StatusWord {
-    int *host = nullptr;
-    int *dev = nullptr;
-};
-StatusWord &status_word()
+const StatusWord &status_word()
 {
+    // Allocated once per process, by the first caller: portable (every device of the process sees it) and mapped.
     static StatusWord w = [] {
         StatusWord v;
         int *h = nullptr;
-        if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+        if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h) {
             *h = 0;
             void *d = nullptr;
             if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
@@ -92,27 +55,41 @@ StatusWord &status_word()
     return w;
 }
 
+// The word is a pinned allocation, which must not happen inside a caller's stream capture: a launch that arrives
+// capturing before the word exists is refused (rtmi_init, or any earlier un-captured call, creates it).
+static std::mutex g_status_mu;
+static bool g_status_made = false;
+int status_word_for(hipStream_t stream, int **dev_out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_status_mu);
+        if (!g_status_made) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(RTMI_ERR_BAD_ARG, "first librtmi launch of the process inside a stream capture: call "
+                                               "rtmi_init (or one un-captured launch) before capturing");
+            (void)status_word();
+            g_status_made = true;
+        }
+    }
+    *dev_out = status_word().dev;
+    return RTMI_OK;
+}
+
 int device_fault(int st)
 {
+    if (st & 8)
+        return fail(RTMI_ERR_BAD_ARG, "a model row of a batch launch had nlayers outside [1, ld_model - 1] (device status "
+                                       "%d): its outputs were filled with NaN", st);
     return fail(RTMI_ERR_HIP, "the fused kernel reported an internal scheduling fault (status %d): results are not valid", st);
 }
 
 // Tuning knobs of the fused kernel, overridable from the environment for A/B runs.
-struct Tuning {
-    int force_path;      // 0 auto, 1 plain kernel, 2 fused kernel
-    int solve_waves;     // resident waves per SIMD of the fused kernel
-    int refill_min;      // idle lanes that trigger a refill
-    int tail_group;      // end-game concentration (records per wave group), 0 = off
-    int retire_max;      // drain: live lanes a retiring wave hands over (0 = off)
-    int promote_age;     // trips after which a local wave hands a source to the express waves (0 = off)
-    unsigned long long *d_stamps = nullptr;  // diagnostic phase clocks of the fused kernel (rtmi_debug_stamps)
-    int diag_fine = 1;                       // ... including the per-trip clocks and counters
-};
-
-Tuning &tuning()
+static std::mutex g_tune_mu;
+static Tuning &tuning_locked()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 16, 256, 8, 10, nullptr};
+        Tuning v{0, 4, 16, 256, 8, 10, nullptr, 1};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;
@@ -132,6 +109,12 @@ Tuning &tuning()
         return v;
     }();
     return t;
+}
+
+Tuning tuning_snapshot()
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    return tuning_locked();
 }
 
 Context &ctx()
@@ -156,10 +139,105 @@ int ensure_ready_locked(Context &c)
     c.cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(rtmi_prepare_kernels());
-    (void)status_word();  // one-time pinned allocation: here, not inside a caller's stream capture
+    int *unused = nullptr;
+    int rc = status_word_for(nullptr, &unused);  // one-time pinned allocation: here, not inside a caller's capture
+    if (rc)
+        return rc;
     c.ready = true;
     return RTMI_OK;
 }
+
+int num_cus_for_current_device()
+{
+    Context &c = ctx();
+    if (c.cus > 0)
+        return c.cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return 256;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 256;
+    return cus;
+}
+
+static bool batch_takes_fused(const Tuning &tn, int64_t nsrc)
+{
+    return tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2);
+}
+
+int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
+{
+    const Tuning tn = tuning_snapshot();
+    if (batch_takes_fused(tn, nsrc)) {
+        int threads = 0, slots = 0;
+        size_t lds = 0;
+        return rtmi_fused_geometry(nsrc, max_nlayers, nmodels, cus, tn.solve_waves, (int)sizeof(double), &threads, &slots,
+                                   &lds);
+    }
+    return rtmi_launch_grid_x(nsrc, nmodels, cus);
+}
+
+int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
+                 int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
+                 const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream)
+{
+    const Tuning tn = tuning_snapshot();
+    int *d_status = nullptr;
+    int rc = status_word_for(stream, &d_status);
+    if (rc)
+        return rc;
+    int gx = 0;
+    if (batch_takes_fused(tn, nsrc)) {
+        rtmi::FusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.d_vels = d_vels;
+        fa.d_depths = d_depths;
+        fa.d_nlayers = d_nlayers;
+        fa.ld_model = ld_model;
+        fa.refill_min = tn.refill_min;
+        fa.tail_group = tn.tail_group;
+        fa.retire_max = tn.retire_max;
+        fa.d_status = d_status;
+        fa.promote_age = tn.promote_age;
+        fa.allow_skip = allow_skip ? 1 : 0;
+        fa.d_src_offset = d_src_offset;
+        fa.d_src_depth = d_src_depth;
+        fa.nsrc = nsrc;
+        fa.d_timeP = d_timeP;
+        fa.d_obs = d_obs;
+        fa.d_partial = d_partial;
+        HIP_TRY(rtmi_launch_fused(&fa, nmodels, max_nlayers, cus, tn.solve_waves, &gx, stream));
+    } else {
+        rtmi::TraceArgs a;
+        memset(&a, 0, sizeof a);
+        a.d_vels = d_vels;
+        a.d_depths = d_depths;
+        a.d_nlayers = d_nlayers;
+        a.ld_model = ld_model;
+        a.d_src_offset = d_src_offset;
+        a.d_src_depth = d_src_depth;
+        a.nsrc = nsrc;
+        a.d_timeP = d_timeP;
+        a.d_obs = d_obs;
+        a.d_partial = d_partial;
+        a.allow_skip = allow_skip ? 1 : 0;
+        a.d_status = d_status;
+        gx = rtmi_launch_grid_x(nsrc, nmodels, cus);
+        HIP_TRY(rtmi_launch_trace(&a, nmodels, max_nlayers, gx, stream));
+    }
+    if (gx_out)
+        *gx_out = gx;
+    return RTMI_OK;
+}
+
+}  // namespace rtmi_host
+
+using namespace rtmi_host;
+
+namespace {
+
+#define RTMI_SMALL_CALL_NSRC 4096  // dff_ / TraceRays calls up to this size run on a mapped pinned buffer
 
 int grow(double **p, size_t *cap, size_t need)
 {
@@ -182,18 +260,167 @@ int check_model(int nlayers)
     return RTMI_OK;
 }
 
-int num_cus_for_current_device()
-{
-    Context &c = ctx();
-    if (c.cus > 0)
-        return c.cus;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess)
-        return 256;
+// ---------------------------------------------------------------------------------------------------------------
+// The drop-in path for large calls: a chunked three-queue pipeline per device.
+//
+// The caller's buffers are ordinary pageable host memory and every byte crosses PCIe once (16 B in, 8 B out per
+// source), so the call is transfer bound: the source arrays are cut into chunks and chunk i+1's upload, chunk i's
+// kernel and chunk i-1's download run on three streams of the device (uploads and downloads use opposite directions
+// of the link).  With RTMI_DEVICES the sources are additionally sharded in contiguous slices over several GPUs
+// ("single forward": no collective, the model is replicated, the host gathers timeP): each GPU has
+// its own link to the host, and each slice is driven by its own host thread.
+// ---------------------------------------------------------------------------------------------------------------
+struct DropinLane {
+    int device = 0;
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        return 256;
-    return cus;
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    double *d_model = nullptr;
+    size_t model_cap = 0;
+    double *d_src = nullptr;  // offset | depth | timeP | p_final of this lane's slice
+    size_t src_cap = 0;
+    std::vector<hipEvent_t> ev_in, ev_k;
+};
+
+struct DropinState {
+    std::vector<std::unique_ptr<DropinLane>> lanes;  // lanes[0] = the bound device
+    bool parsed = false;
+    std::vector<int> extra_devices;                  // RTMI_DEVICES beyond the bound device (may repeat a device)
+    int64_t chunk = 0;                               // sources per chunk
+    int64_t shard_min = 0;                           // slices smaller than this are not worth another device
+};
+DropinState g_dropin;
+
+int lane_ready(DropinLane &L, int device, size_t nevents)
+{
+    HIP_TRY(hipSetDevice(device));
+    if (!L.s_in) {
+        L.device = device;
+        HIP_TRY(hipDeviceGetAttribute(&L.cus, hipDeviceAttributeMultiprocessorCount, device));
+        HIP_TRY(hipStreamCreateWithFlags(&L.s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&L.s_k, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&L.s_out, hipStreamNonBlocking));
+        HIP_TRY(rtmi_prepare_kernels());
+    }
+    while (L.ev_in.size() < nevents) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        L.ev_in.push_back(a);
+        L.ev_k.push_back(b);
+    }
+    return RTMI_OK;
+}
+
+void parse_dropin_env_locked(Context &c)
+{
+    if (g_dropin.parsed)
+        return;
+    g_dropin.parsed = true;
+    g_dropin.chunk = 262144;
+    if (const char *e = getenv("RTMI_DROPIN_CHUNK"))
+        if (atoll(e) >= 4096)
+            g_dropin.chunk = atoll(e) / 64 * 64;
+    g_dropin.shard_min = 131072;
+    if (const char *e = getenv("RTMI_SHARD_MIN"))
+        if (atoll(e) >= 1)
+            g_dropin.shard_min = atoll(e);
+    g_dropin.lanes.emplace_back(new DropinLane);
+    const char *e = getenv("RTMI_DEVICES");
+    if (!e || !*e)
+        return;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess)
+        return;
+    if (!strcmp(e, "all")) {
+        for (int d = 0; d < ndev; ++d)
+            if (d != c.device)
+                g_dropin.extra_devices.push_back(d);
+    } else {
+        // comma-separated list; the bound device takes the first slice, every further entry one more slice (an
+        // entry may name the bound device again: two pipelines on one GPU, used by the tests on a 1-GPU box)
+        bool first = true;
+        for (const char *q = e; *q;) {
+            const int d = atoi(q);
+            if (d >= 0 && d < ndev && !first)
+                g_dropin.extra_devices.push_back(d);
+            first = false;
+            while (*q && *q != ',')
+                ++q;
+            if (*q == ',')
+                ++q;
+        }
+    }
+    for (size_t i = 0; i < g_dropin.extra_devices.size(); ++i)
+        g_dropin.lanes.emplace_back(new DropinLane);
+}
+
+// One slice [k0, k0 + n) of the call on one device.
+int run_slice(DropinLane &L, int device, const double *vels, const double *depths, int nlayers, const double *src_offset,
+              const double *src_depth, int64_t n, double *timeP, double *p_out, int64_t chunk, const Tuning &tn)
+{
+    const int64_t nch = (n + chunk - 1) / chunk;
+    int rc = lane_ready(L, device, (size_t)nch);
+    if (rc)
+        return rc;
+    rc = grow(&L.d_model, &L.model_cap, (size_t)2 * nlayers + 1);
+    if (rc)
+        return rc;
+    rc = grow(&L.d_src, &L.src_cap, (size_t)4 * n);
+    if (rc)
+        return rc;
+    int *d_status = nullptr;
+    rc = status_word_for(nullptr, &d_status);
+    if (rc)
+        return rc;
+    double *d_vels = L.d_model, *d_depths = L.d_model + nlayers + 1;
+    double *d_off = L.d_src, *d_dep = L.d_src + n, *d_t = L.d_src + 2 * n, *d_p = L.d_src + 3 * n;
+    HIP_TRY(hipMemcpyAsync(d_vels, vels, (size_t)(nlayers + 1) * sizeof(double), hipMemcpyHostToDevice, L.s_in));
+    HIP_TRY(hipMemcpyAsync(d_depths, depths, (size_t)nlayers * sizeof(double), hipMemcpyHostToDevice, L.s_in));
+    for (int64_t c = 0; c < nch; ++c) {
+        const int64_t k0 = c * chunk, m = std::min(chunk, n - k0);
+        HIP_TRY(hipMemcpyAsync(d_off + k0, src_offset + k0, (size_t)m * sizeof(double), hipMemcpyHostToDevice, L.s_in));
+        HIP_TRY(hipMemcpyAsync(d_dep + k0, src_depth + k0, (size_t)m * sizeof(double), hipMemcpyHostToDevice, L.s_in));
+        HIP_TRY(hipEventRecord(L.ev_in[c], L.s_in));
+        HIP_TRY(hipStreamWaitEvent(L.s_k, L.ev_in[c], 0));
+        const bool fused = tn.force_path != 1 && (m >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
+        if (fused) {
+            rtmi::FusedArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.d_vels = d_vels;
+            fa.d_depths = d_depths;
+            fa.nlayers = nlayers;
+            fa.refill_min = tn.refill_min;
+            fa.tail_group = tn.tail_group;
+            fa.retire_max = tn.retire_max;
+            fa.d_status = d_status;
+            fa.promote_age = tn.promote_age;
+            fa.d_src_offset = d_off + k0;
+            fa.d_src_depth = d_dep + k0;
+            fa.nsrc = m;
+            fa.d_timeP = d_t + k0;
+            fa.d_p_final = p_out ? d_p + k0 : nullptr;
+            HIP_TRY(rtmi_launch_fused(&fa, 1, nlayers, L.cus, tn.solve_waves, nullptr, L.s_k));
+        } else {
+            rtmi::TraceArgs a;
+            memset(&a, 0, sizeof a);
+            a.d_vels = d_vels;
+            a.d_depths = d_depths;
+            a.nlayers = nlayers;
+            a.d_src_offset = d_off + k0;
+            a.d_src_depth = d_dep + k0;
+            a.nsrc = m;
+            a.d_timeP = d_t + k0;
+            a.d_p_final = p_out ? d_p + k0 : nullptr;
+            HIP_TRY(rtmi_launch_trace(&a, 1, nlayers, rtmi_launch_grid_x(m, 1, L.cus), L.s_k));
+        }
+        HIP_TRY(hipEventRecord(L.ev_k[c], L.s_k));
+        HIP_TRY(hipStreamWaitEvent(L.s_out, L.ev_k[c], 0));
+        HIP_TRY(hipMemcpyAsync(timeP + k0, d_t + k0, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, L.s_out));
+        if (p_out)
+            HIP_TRY(hipMemcpyAsync(p_out + k0, d_p + k0, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, L.s_out));
+    }
+    HIP_TRY(hipStreamSynchronize(L.s_out));
+    return RTMI_OK;
 }
 
 // The reference-shaped call: host buffers in, host buffers out, optional rays.dat.
@@ -249,28 +476,49 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
             return rtmi_write_rays_dat("rays.dat", vels, depths, nlayers, src_offset, src_depth, h + nm + 3 * n, nsrc);
         return RTMI_OK;
     }
-    rc = grow(&c.d_model, &c.model_cap, (size_t)2 * nlayers + 1);
-    if (rc)
-        return rc;
-    rc = grow(&c.d_src, &c.src_cap, 4 * n);
-    if (rc)
-        return rc;
-    double *d_vels = c.d_model, *d_depths = c.d_model + nlayers + 1;
-    double *d_off = c.d_src, *d_dep = c.d_src + n, *d_t = c.d_src + 2 * n, *d_p = c.d_src + 3 * n;
-    HIP_TRY(hipMemcpyAsync(d_vels, vels, (size_t)(nlayers + 1) * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    HIP_TRY(hipMemcpyAsync(d_depths, depths, (size_t)nlayers * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    HIP_TRY(hipMemcpyAsync(d_off, src_offset, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    HIP_TRY(hipMemcpyAsync(d_dep, src_depth, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    rc = rtmi_trace_device(d_vels, d_depths, nlayers, d_off, d_dep, nsrc, d_t, want_p ? d_p : nullptr, c.stream);
-    if (rc)
-        return rc;
-    HIP_TRY(hipMemcpyAsync(timeP, d_t, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    parse_dropin_env_locked(c);
+    const Tuning tn = tuning_snapshot();
     std::vector<double> p;
-    if (want_p) {
+    if (want_p)
         p.resize(n);
-        HIP_TRY(hipMemcpyAsync(p.data(), d_p, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    // contiguous slices over the lanes (the bound device first); a slice below shard_min is not worth a device
+    int nl_use = (int)g_dropin.lanes.size();
+    while (nl_use > 1 && (int64_t)n / nl_use < g_dropin.shard_min)
+        --nl_use;
+    std::vector<std::future<int>> jobs;
+    std::vector<std::string> errs((size_t)nl_use);
+    int rc_all = RTMI_OK;
+    for (int i = nl_use - 1; i >= 0; --i) {
+        const int64_t k0 = (int64_t)n * i / nl_use, k1 = (int64_t)n * (i + 1) / nl_use;
+        const int dev = i == 0 ? c.device : g_dropin.extra_devices[(size_t)i - 1];
+        DropinLane *L = g_dropin.lanes[(size_t)i].get();
+        auto job = [=, &tn, &errs, &p]() {
+            const int r = run_slice(*L, dev, vels, depths, nlayers, src_offset + k0, src_depth + k0, k1 - k0, timeP + k0,
+                                    want_p ? p.data() + k0 : nullptr, g_dropin.chunk, tn);
+            if (r)
+                errs[(size_t)i] = g_err;  // the worker thread's message
+            return r;
+        };
+        if (i == 0) {
+            rc_all = job();  // the bound device's slice on the calling thread
+        } else {
+            jobs.push_back(std::async(std::launch::async, job));
+        }
     }
-    HIP_TRY(hipStreamSynchronize(c.stream));
+    for (auto &j : jobs) {
+        const int r = j.get();
+        if (r && !rc_all)
+            rc_all = r;
+    }
+    HIP_TRY(hipSetDevice(c.device));
+    if (rc_all) {
+        for (const auto &e : errs)
+            if (!e.empty()) {
+                g_err = e;
+                break;
+            }
+        return rc_all;
+    }
     if (int st = rtmi_device_status())
         return device_fault(st);
     if (want_p)
@@ -336,12 +584,8 @@ int rtmi_init(int device)
     Context &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     if (c.ready && c.device != device) {
-        // rebind: drop the old context's buffers
+        // rebind: drop the old context's buffers and the drop-in pipelines
         (void)hipSetDevice(c.device);
-        if (c.d_model)
-            (void)hipFree(c.d_model);
-        if (c.d_src)
-            (void)hipFree(c.d_src);
         if (c.d_set)
             (void)hipFree(c.d_set);
         if (c.d_lk)
@@ -354,10 +598,27 @@ int rtmi_init(int device)
         c.set_cap = c.lk_cap = c.pin_cap = c.small_cap = 0;
         c.set_n = 0;
         c.set_has_obs = false;
+        ++c.set_generation;
+        for (auto &L : g_dropin.lanes) {
+            if (!L->s_in)
+                continue;
+            (void)hipSetDevice(L->device);
+            if (L->d_model)
+                (void)hipFree(L->d_model);
+            if (L->d_src)
+                (void)hipFree(L->d_src);
+            for (hipEvent_t e : L->ev_in)
+                (void)hipEventDestroy(e);
+            for (hipEvent_t e : L->ev_k)
+                (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(L->s_in);
+            (void)hipStreamDestroy(L->s_k);
+            (void)hipStreamDestroy(L->s_out);
+        }
+        g_dropin = DropinState();
+        (void)hipSetDevice(c.device);
         if (c.stream)
             (void)hipStreamDestroy(c.stream);
-        c.d_model = c.d_src = nullptr;
-        c.model_cap = c.src_cap = 0;
         c.stream = nullptr;
         c.cus = 0;
         c.ready = false;
@@ -370,7 +631,8 @@ int rtmi_set_option(const char *name, int value)
 {
     if (!name)
         return fail(RTMI_ERR_BAD_ARG, "NULL option name");
-    Tuning &t = tuning();
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    Tuning &t = tuning_locked();
     if (!strcmp(name, "path")) {
         if (value < 0 || value > 2)
             return fail(RTMI_ERR_BAD_ARG, "path must be 0 (auto), 1 (plain) or 2 (fused)");
@@ -409,9 +671,18 @@ int rtmi_device_status(void)
     return w.host ? *(volatile int *)w.host : 0;
 }
 
+int rtmi_clear_device_status(void)
+{
+    const StatusWord &w = status_word();
+    if (!w.host)
+        return 0;
+    return __atomic_exchange_n(w.host, 0, __ATOMIC_SEQ_CST);
+}
+
 int rtmi_debug_stamps(unsigned long long *d_stamps)
 {
-    tuning().d_stamps = d_stamps;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tuning_locked().d_stamps = d_stamps;
     return RTMI_OK;
 }
 
@@ -436,7 +707,11 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         return RTMI_OK;
     if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
         return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
-    const Tuning tn = tuning();
+    const Tuning tn = tuning_snapshot();
+    int *d_status = nullptr;
+    rc = status_word_for((hipStream_t)stream, &d_status);
+    if (rc)
+        return rc;
     const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
     if (fused) {
         rtmi::FusedArgs fa;
@@ -447,7 +722,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.d_status = status_word().dev;
+        fa.d_status = d_status;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
@@ -522,7 +797,15 @@ int rtmi_set_sources(const double *src_offset, const double *src_depth, const do
         return device_fault(st);
     c.set_n = nsrc;
     c.set_has_obs = obs != nullptr;
+    ++c.set_generation;
     return RTMI_OK;
+}
+
+uint64_t rtmi_sources_generation(void)
+{
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return c.set_n > 0 ? c.set_generation : 0;
 }
 
 int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t *nlayers, int ld_model, int nmodels,
@@ -536,9 +819,12 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
         return fail(RTMI_ERR_BAD_ARG, "NULL argument");
     if (ld_model < 2 || ld_model - 1 > RTMI_MAX_LAYERS)
         return fail(RTMI_ERR_BAD_ARG, "ld_model = %d outside [2, %d]", ld_model, RTMI_MAX_LAYERS + 1);
-    for (int m = 0; m < nmodels; ++m)
+    int max_nl = 1;  // the launch is sized for the largest model of THIS batch, not for the row stride
+    for (int m = 0; m < nmodels; ++m) {
         if (nlayers[m] < 1 || nlayers[m] > ld_model - 1)
             return fail(RTMI_ERR_BAD_ARG, "nlayers[%d] = %d outside [1, ld_model - 1]", m, nlayers[m]);
+        max_nl = nlayers[m] > max_nl ? nlayers[m] : max_nl;
+    }
     Context &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     if (!c.ready || c.set_n < 1 || !c.set_has_obs)
@@ -571,41 +857,11 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
     HIP_TRY(hipMemcpyAsync(c.d_lk, h, n_in * sizeof(double), hipMemcpyHostToDevice, c.stream));
     const size_t n = (size_t)c.set_n;
     // travel times are not materialised: only the residual sums leave the kernel
-    rtmi::FusedArgs fa;
-    memset(&fa, 0, sizeof fa);
-    const Tuning tn = tuning();
     int gx = 0;
-    if (tn.force_path != 1 && (c.set_n >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2)) {
-        fa.d_vels = d_v;
-        fa.d_depths = d_d;
-        fa.d_nlayers = d_nl;
-        fa.ld_model = ld_model;
-        fa.refill_min = tn.refill_min;
-        fa.tail_group = tn.tail_group;
-        fa.retire_max = tn.retire_max;
-        fa.d_status = status_word().dev;
-        fa.promote_age = tn.promote_age;
-        fa.d_src_offset = c.d_set;
-        fa.d_src_depth = c.d_set + n;
-        fa.nsrc = c.set_n;
-        fa.d_obs = c.d_set + 2 * n;
-        fa.d_partial = d_work;
-        HIP_TRY(rtmi_launch_fused(&fa, nmodels, ld_model - 1, c.cus, tn.solve_waves, &gx, c.stream));
-    } else {
-        rtmi::TraceArgs a;
-        memset(&a, 0, sizeof a);
-        a.d_vels = d_v;
-        a.d_depths = d_d;
-        a.d_nlayers = d_nl;
-        a.ld_model = ld_model;
-        a.d_src_offset = c.d_set;
-        a.d_src_depth = c.d_set + n;
-        a.nsrc = c.set_n;
-        a.d_obs = c.d_set + 2 * n;
-        a.d_partial = d_work;
-        gx = rtmi_launch_grid_x(c.set_n, nmodels, c.cus);
-        HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, c.stream));
-    }
+    rc = launch_batch(d_v, d_d, d_nl, ld_model, nmodels, max_nl, c.d_set, c.d_set + n, c.set_n, nullptr, c.d_set + 2 * n,
+                      d_work, false, c.cus, &gx, c.stream);
+    if (rc)
+        return rc;
     HIP_TRY(rtmi_launch_loglike(d_work, gx, d_sd, c.set_n, nmodels, d_out, d_out + nm, c.stream));
     HIP_TRY(hipMemcpyAsync(h + n_in, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
@@ -629,7 +885,11 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         return RTMI_OK;
     if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
         return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
-    const Tuning tn = tuning();
+    const Tuning tn = tuning_snapshot();
+    int *d_status = nullptr;
+    rc = status_word_for((hipStream_t)stream, &d_status);
+    if (rc)
+        return rc;
     const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
     if (fused) {
         rtmi::FusedArgsT<float> fa;
@@ -640,7 +900,7 @@ int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayer
         fa.refill_min = tn.refill_min;
         fa.tail_group = tn.tail_group;
         fa.retire_max = tn.retire_max;
-        fa.d_status = status_word().dev;
+        fa.d_status = d_status;
         fa.promote_age = tn.promote_age;
         fa.d_src_offset = d_src_offset;
         fa.d_src_depth = d_src_depth;
@@ -698,47 +958,14 @@ int rtmi_trace_batch_device(const double *d_vels, const double *d_depths, const 
         return fail(RTMI_ERR_BAD_ARG, "logL needs d_obs, d_sd, d_logL and d_work together");
     if (!want_ll && !d_timeP)
         return fail(RTMI_ERR_BAD_ARG, "nothing to compute: d_timeP and d_logL both NULL");
-    rtmi::TraceArgs a;
-    memset(&a, 0, sizeof a);
-    a.d_vels = d_vels;
-    a.d_depths = d_depths;
-    a.d_nlayers = d_nlayers;
-    a.nlayers = 0;
-    a.ld_model = ld_model;
-    a.d_src_offset = d_src_offset;
-    a.d_src_depth = d_src_depth;
-    a.nsrc = nsrc;
-    a.d_timeP = d_timeP;
-    a.d_p_final = nullptr;
-    a.d_obs = want_ll ? d_obs : nullptr;
-    a.d_partial = (double *)d_work;
-    const Tuning tn = tuning();
+    // d_nlayers lives on the device: the launch is sized for the row stride, and the kernels check every
+    // d_nlayers[m] against it (fault bit 8 + NaN outputs for a row outside [1, ld_model - 1])
     int gx = 0;
-    const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2);
-    if (fused) {
-        rtmi::FusedArgs fa;
-        memset(&fa, 0, sizeof fa);
-        fa.d_vels = d_vels;
-        fa.d_depths = d_depths;
-        fa.d_nlayers = d_nlayers;
-        fa.ld_model = ld_model;
-        fa.refill_min = tn.refill_min;
-        fa.tail_group = tn.tail_group;
-        fa.retire_max = tn.retire_max;
-        fa.d_status = status_word().dev;
-        fa.promote_age = tn.promote_age;
-        fa.d_src_offset = d_src_offset;
-        fa.d_src_depth = d_src_depth;
-        fa.nsrc = nsrc;
-        fa.d_timeP = d_timeP;
-        fa.d_obs = want_ll ? d_obs : nullptr;
-        fa.d_partial = (double *)d_work;
-        HIP_TRY(rtmi_launch_fused(&fa, nmodels, ld_model - 1, num_cus_for_current_device(), tn.solve_waves, &gx,
-                                  (hipStream_t)stream));
-    } else {
-        gx = rtmi_launch_grid_x(nsrc, nmodels, num_cus_for_current_device());
-        HIP_TRY(rtmi_launch_trace(&a, nmodels, ld_model - 1, gx, (hipStream_t)stream));
-    }
+    const int rc = launch_batch(d_vels, d_depths, d_nlayers, ld_model, nmodels, ld_model - 1, d_src_offset, d_src_depth,
+                                nsrc, d_timeP, want_ll ? d_obs : nullptr, (double *)d_work, false,
+                                num_cus_for_current_device(), &gx, (hipStream_t)stream);
+    if (rc)
+        return rc;
     if (want_ll)
         HIP_TRY(rtmi_launch_loglike((const double *)d_work, gx, d_sd, nsrc, nmodels, d_logL, nullptr,
                                     (hipStream_t)stream));

@@ -31,6 +31,9 @@ struct TraceArgsT {
     T *d_p_final;  // [nsrc] or NULL (single model only)
     const T *d_obs;  // [nsrc] or NULL
     T *d_partial;    // [nmodels][grid_x] per-workgroup sums of squared residuals
+    int max_nlayers; // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers] (the LDS table is sized for it)
+    int allow_skip;  // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
+    int *d_status;   // sticky fault word (host-mapped) or NULL: bit 8 = a d_nlayers[m] out of range
 };
 typedef TraceArgsT<double> TraceArgs;
 
@@ -56,7 +59,10 @@ struct FusedArgsT {
     T *d_p_final;           // [nsrc] or NULL (single model only)
     const T *d_obs;         // [nsrc] or NULL
     T *d_partial;           // [nmodels][grid.x] per-workgroup sums of squared residuals
-    int *d_status;                 // sticky fault word (host-mapped) or NULL: a bounded wait of the hand-over ring ran out
+    int *d_status;                 // sticky fault word (host-mapped) or NULL: a bounded wait of the hand-over ring ran
+                                   // out (bits 1, 2, 4) or a d_nlayers[m] was out of range (bit 8)
+    int max_nlayers;               // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers]
+    int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };

@@ -94,6 +94,29 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
     return tt;
 }
 
+// A model row whose d_nlayers[m] cannot be used (whole workgroup, before anything touches LDS).  Returns true when
+// the workgroup must leave: 0 with allow_skip is an inactive row (nothing written but a zero partial sum); anything
+// else outside [1, max_nlayers] would overrun the LDS layer table, so the row is reported through the fault word
+// (bit 8) and its outputs are filled with NaN -- loud, never silently wrong.
+template <typename T>
+__device__ __forceinline__ bool reject_model_row(int nlayers, int max_nlayers, int allow_skip, int *d_status,
+                                                 T *timeP_row, int64_t nsrc, T *partial_slot)
+{
+    if (nlayers >= 1 && nlayers <= max_nlayers)
+        return false;
+    const bool skip = allow_skip && nlayers == 0;
+    if (!skip) {
+        if (threadIdx.x == 0 && blockIdx.x == 0 && d_status)
+            atomicOr(d_status, 8);
+        if (timeP_row)
+            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nsrc; k += (int64_t)gridDim.x * blockDim.x)
+                timeP_row[k] = T(__builtin_nan(""));
+    }
+    if (partial_slot && threadIdx.x == 0)
+        *partial_slot = skip ? T(0.0) : T(__builtin_nan(""));
+    return true;
+}
+
 // grid.x: source tiles (grid-stride), grid.y: models.
 template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS>
 __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
@@ -102,6 +125,10 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     const int nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
+    if (a.d_nlayers && reject_model_row<T>(nlayers, a.max_nlayers, a.allow_skip, a.d_status,
+                                           WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
+                                           WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr))
+        return;
     const LayerTable<T> t = carve_table(lds, nlayers);
     stage_model(t, a.d_vels + (int64_t)m * a.ld_model, a.d_depths + (int64_t)m * a.ld_model, nlayers);
 
@@ -195,6 +222,10 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int m = blockIdx.y;
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
+    if (a.d_nlayers && reject_model_row<T>(a.nlayers, a.max_nlayers, a.allow_skip, a.d_status,
+                                           WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
+                                           WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr))
+        return;
     a.d_vels += (int64_t)m * a.ld_model;
     a.d_depths += (int64_t)m * a.ld_model;
     if (WANT_T)
@@ -884,10 +915,12 @@ extern "C" int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus)
 }
 
 template <typename T>
-static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &a, int nmodels, int max_nlayers, int grid_x,
+static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &args, int nmodels, int max_nlayers, int grid_x,
                                  hipStream_t stream)
 {
     using namespace rtmi;
+    TraceArgsT<T> a = args;
+    a.max_nlayers = max_nlayers;  // what the LDS table below is sized for: the kernel checks d_nlayers[m] against it
     const size_t lds_bytes = RTMI_TABLE_ELEMS(max_nlayers, false) * sizeof(T);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
@@ -1025,6 +1058,7 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
             return e;
     }
     FusedArgsT<T> a = args;
+    a.max_nlayers = max_nlayers;  // what the LDS table is sized for: the kernel checks d_nlayers[m] against it
     a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;  // launch-wide: the layer tables carry one row per stack height
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;

@@ -1,0 +1,875 @@
+// rtmi_pt.hip -- the Metropolis-Hastings sweep of the reversible-jump tempering sampler, resident on the GPU.
+//
+// What the reference does per MCMC step and chain (one MPI rank each):
+//   EXPLORE_MH_NOVARPAR   birth / death / perturbation of every (node, parameter)   prjmh_temper_rf.f90:637-761
+//   EXPLORE_MH            sigma proposal                                            prjmh_temper_rf.f90:521-634
+//   TEMPSWP_MH            temperature exchange between two chains                   prjmh_temper_rf.f90:1329-1357
+// with LOGLHOOD -> TraceRays behind every decision (loglhood.f90:128-199).
+//
+// Here the chains of one process (one GPU) advance in lock-step and NOTHING of a sweep runs on the host:
+//   * chain state (k, node depths and velocities, sigma, logL, SS, beta, the position of the chain's random stream)
+//     lives in HBM for the lifetime of the handle;
+//   * a proposal slot is two launches on one stream: pt_step_kernel (one thread per chain: accept/reject the
+//     previous slot from the residual sums the likelihood launch left behind, then draw this slot's proposal, check
+//     CHECKBOUNDS and write the proposed model as a row of the batch) and the batched likelihood launch of
+//     rtmi_kernels.hip over the handle's resident sources (rows of chains without a valid proposal are marked
+//     inactive and cost nothing);
+//   * a sweep = birth/death slot + one slot per (node, parameter) + the sigma move, captured once per slot count
+//     as a hipGraph and replayed; the temperature exchange is one all-gather of logL (RCCL, rtmi_comm.cpp) plus
+//     pt_swap_kernel, and pt_record_kernel appends the T = 1 chains to a sample ring -- so rtmi_pt_run enqueues whole
+//     runs without a single host synchronisation.
+// The rules themselves (proposals, prior, bounds, acceptance, pairing) are in rtmi_pt_rules.h, shared with the host.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "rtmi_host.h"
+#include "rtmi_pt_rules.h"
+
+using namespace rtmi_host;
+namespace R = rtmi_pt_rules;
+
+namespace {
+
+enum : int { PT_NONE = -1, PT_BD = 0, PT_MH = 1, PT_EVAL = 2 };
+
+// Everything the kernels need; passed by value.  Pointers are device pointers owned by the handle.
+struct PtDev {
+    int nchains, K, ld_model, gx;
+    int64_t ndata;
+    rtmi_pt_prior pr;
+    uint64_t seed;
+    uint32_t stream_id;
+    const double *logpk;  // [kmax + 2] Poisson prior, log
+    // chain state
+    int *k;
+    double *z, *v;        // [nchains][K]
+    double *sd, *logL, *ss, *beta;
+    unsigned long long *ctr;
+    // proposal of the current slot
+    int *pk, *pactive;    // pactive: 0 none, 1 proposal awaiting its decision, 2 evaluation of the current state
+    double *pz, *pv, *plp;
+    // batch rows of the likelihood launch and its per-workgroup residual sums
+    double *V, *D;        // [nchains][ld_model]
+    int32_t *NL;          // 0 = inactive row
+    const double *partial;  // [nchains][gx]
+    long long *stats;     // [nchains][8]: acc/prop birth-death, acc/prop perturbation, acc/prop sigma, models evaluated, -
+};
+
+__device__ __forceinline__ void load_nodes(const double *src, double *dst, int k)
+{
+    for (int i = 0; i < k; ++i)
+        dst[i] = src[i];
+}
+
+// One thread per chain: [decide the previous slot] [sigma move] [propose the next slot].
+__global__ void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nchains)
+        return;
+    const rtmi_pt_prior &p = d.pr;
+    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, d.ctr[c]);
+    int k = d.k[c];
+    double *zc = d.z + (size_t)c * d.K, *vc = d.v + (size_t)c * d.K;
+    double *pz = d.pz + (size_t)c * d.K, *pv = d.pv + (size_t)c * d.K;
+    long long *st = d.stats + (size_t)c * 8;
+
+    // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
+    const int act = d.pactive[c];
+    if (decide != PT_NONE && act != 0) {
+        double s = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
+        for (int i = 0; i < d.gx; ++i)
+            s = s + d.partial[(size_t)c * d.gx + i];
+        const double logl_new = R::gaussian_loglike(s, d.ndata, d.sd[c]);
+        if (act == 2) {
+            d.ss[c] = s;
+            d.logL[c] = logl_new;
+        } else {
+            double lr = d.plp[c] + (logl_new - d.logL[c]) * d.beta[c];
+            if (lr > 50.0)
+                lr = 50.0;
+            st[2 * decide + 1] += 1;
+            if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
+                k = d.pk[c];
+                d.k[c] = k;
+                load_nodes(pz, zc, k);
+                load_nodes(pv, vc, k);
+                d.ss[c] = s;
+                d.logL[c] = logl_new;
+                st[2 * decide] += 1;
+            }
+        }
+        d.pactive[c] = 0;
+    }
+
+    // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
+    if (sigma) {
+        if (R::philox_uniform(rng) >= 0.10) {
+            const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
+            const double sd_new = d.sd[c] + step * R::philox_normal(rng);
+            st[5] += 1;
+            if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
+                const double logl_new = R::gaussian_loglike(d.ss[c], d.ndata, sd_new);
+                double lr = (logl_new - d.logL[c]) * d.beta[c];
+                if (lr > 50.0)
+                    lr = 50.0;
+                if (!(R::philox_uniform(rng) >= exp(lr))) {
+                    d.sd[c] = sd_new;
+                    d.logL[c] = logl_new;
+                    st[4] += 1;
+                }
+            }
+        }
+    }
+
+    // ---- proposal of the next slot --------------------------------------------------------------------------------
+    if (propose != PT_NONE) {
+        double qz[RTMI_PT_MAX_K], qv[RTMI_PT_MAX_K];
+        int ord[RTMI_PT_MAX_K];
+        load_nodes(zc, qz, k);
+        load_nodes(vc, qv, k);
+        int qk = k;
+        double lp = 0.0;
+        bool have = false;
+        if (propose == PT_BD) {
+            // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
+            if (p.kmin != p.kmax) {
+                const double u = R::philox_uniform(rng);
+                int move;
+                if (k == p.kmax)
+                    move = (u <= 0.3333) ? 2 : 0;
+                else if (k == p.kmin)
+                    move = (u <= 0.3333) ? 1 : 0;
+                else
+                    move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
+                if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
+                    qz[k] = (p.hmx - p.hmin) * R::philox_uniform(rng);
+                    qv[k] = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
+                    qk = k + 1;
+                    lp = d.logpk[k + 1] - d.logpk[k];
+                    have = true;
+                } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
+                    int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
+                    if (idel > k - 1)
+                        idel = k - 1;
+                    for (int i = idel; i + 1 < k; ++i) {
+                        qz[i] = qz[i + 1];
+                        qv[i] = qv[i + 1];
+                    }
+                    qk = k - 1;
+                    lp = d.logpk[k - 1] - d.logpk[k];
+                    have = true;
+                }
+            }
+        } else if (ivo < k) {
+            // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
+            const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
+            const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
+            if (ipar == 0)
+                qz[ivo] += step;
+            else
+                qv[ivo] += step;
+            have = true;
+        }
+        int nl = 0;
+        if (have) {
+            if (R::inside_bounds(qz, qv, qk, p, ord)) {
+                nl = R::pack_model(qz, qv, qk, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
+                load_nodes(qz, pz, qk);
+                load_nodes(qv, pv, qk);
+                d.pk[c] = qk;
+                d.plp[c] = lp;
+                d.pactive[c] = 1;
+                st[6] += 1;  // a model that goes through the likelihood
+            } else {
+                st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)
+            }
+        }
+        d.NL[c] = nl;
+    }
+    d.ctr[c] = rng.index;
+}
+
+// The current state of every chain as batch rows (rtmi_pt_evaluate).
+__global__ void pt_pack_current_kernel(PtDev d)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nchains)
+        return;
+    const int k = d.k[c];
+    int ord[RTMI_PT_MAX_K];
+    const double *zc = d.z + (size_t)c * d.K, *vc = d.v + (size_t)c * d.K;
+    R::sorted_order(zc, k, ord);
+    d.NL[c] = R::pack_model(zc, vc, k, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
+    d.pactive[c] = 2;
+}
+
+// Temperature exchange: thread 0 runs the shared deterministic pairing over ALL chains (every rank the same), then
+// every thread refreshes the temperature of its local chain.
+__global__ void pt_swap_kernel(int nct, int first, int nloc, const double *logl_all, int *level,
+                               const double *beta_of_level, uint64_t seed, uint64_t round, int *order, long long *swstats,
+                               double *beta)
+{
+    if (threadIdx.x == 0) {
+        long long prop = 0;
+        const int acc = R::swap_decide(nct, logl_all, level, beta_of_level, seed, round, order, &prop);
+        swstats[0] += acc;
+        swstats[1] += prop;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < nloc; c += blockDim.x)
+        beta[c] = beta_of_level[level[first + c]];
+}
+
+// Append the chains that are at T = 1 (level 0) to the sample ring: {sweep, chain, k, sd, logL, z[K], v[K]}.
+__global__ void pt_record_kernel(PtDev d, const int *level, int first, long long sweep, int cap, int *count,
+                                 long long *s_meta, double *s_val)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nchains)
+        return;
+    if (level ? level[first + c] != 0 : d.beta[c] != 1.0)
+        return;
+    const int i = atomicAdd(count, 1);
+    if (i >= cap)
+        return;  // ring full: counted, dropped (the host sees count > capacity)
+    const int k = d.k[c];
+    s_meta[(size_t)i * 3 + 0] = sweep;
+    s_meta[(size_t)i * 3 + 1] = first + c;
+    s_meta[(size_t)i * 3 + 2] = k;
+    double *o = s_val + (size_t)i * (2 + 2 * d.K);
+    o[0] = d.sd[c];
+    o[1] = d.logL[c];
+    for (int j = 0; j < k; ++j) {
+        o[2 + j] = d.z[(size_t)c * d.K + j];
+        o[2 + d.K + j] = d.v[(size_t)c * d.K + j];
+    }
+}
+
+}  // namespace
+
+struct rtmi_pt {
+    std::mutex mu;
+    int device = 0, cus = 0;
+    hipStream_t stream = nullptr;
+    PtDev d;
+    int nchains = 0, K = 0, ld_model = 0, max_nl = 1;
+    int64_t nsrc = 0;
+    // the handle's own copy of the source set (offset | depth | obs)
+    double *d_set = nullptr;
+    // one slab for the doubles, one for the integers
+    double *d_f64 = nullptr;
+    int *d_i32 = nullptr;
+    unsigned long long *d_u64 = nullptr;
+    double *d_partial = nullptr, *d_logpk = nullptr;
+    // ladder (temperature exchange)
+    int nct = 0, first = 0, nlevels = 0;
+    int *d_level = nullptr, *d_order = nullptr;
+    double *d_logl_all = nullptr, *d_beta_of_level = nullptr;
+    long long *d_swstats = nullptr;
+    uint64_t round = 0;
+    // sample ring
+    int s_cap = 0;
+    int *d_s_count = nullptr;
+    long long *d_s_meta = nullptr;
+    double *d_s_val = nullptr;
+    long long sweeps_done = 0;
+    // captured sweeps, by number of node slots
+    std::map<int, hipGraphExec_t> graphs;
+    bool use_graph = true;
+    int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
+    int64_t launches = 0, models = 0;
+};
+
+namespace {
+
+int blocks_for(int n) { return (n + 63) / 64; }
+
+int launch_likelihood(rtmi_pt *h)
+{
+    int gx = 0;
+    const size_t n = (size_t)h->nsrc;
+    int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
+                          nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream);
+    if (rc)
+        return rc;
+    if (gx != h->d.gx)
+        return fail(RTMI_ERR_HIP, "rtmi_pt: launch geometry changed (%d workgroups per model, handle sized for %d); do not "
+                                  "change the scheduling knobs while a handle exists", gx, h->d.gx);
+    return RTMI_OK;
+}
+
+// One sweep with `nslots_k` node slots enqueued on the handle's stream (directly, or into a capture).
+int enqueue_sweep(rtmi_pt *h, int nslots_k)
+{
+    const dim3 g(blocks_for(h->nchains)), b(64);
+    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, (int)PT_NONE, 0, (int)PT_BD, 0, 0);
+    int rc = launch_likelihood(h);
+    if (rc)
+        return rc;
+    int prev = PT_BD;
+    for (int ivo = 0; ivo < nslots_k; ++ivo)
+        for (int ipar = 0; ipar < 2; ++ipar) {
+            if (ivo == 0 && ipar == 0)
+                continue;  // the surface node's depth is not a parameter (:727)
+            hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, prev, 0, (int)PT_MH, ivo, ipar);
+            rc = launch_likelihood(h);
+            if (rc)
+                return rc;
+            prev = PT_MH;
+        }
+    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, prev, 1, (int)PT_NONE, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return RTMI_OK;
+}
+
+int sweep_once(rtmi_pt *h)
+{
+    // perturbation slots cover every node a chain can have during this sweep: k grows by at most one per sweep
+    const int kmax = h->d.pr.kmax;
+    int ks = h->kbound + 1;
+    if (ks > kmax)
+        ks = kmax;
+    h->kbound = ks;
+    h->launches += 2 * ks;
+    if (!h->use_graph)
+        return enqueue_sweep(h, ks);
+    auto it = h->graphs.find(ks);
+    if (it == h->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_sweep(h, ks);
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc)
+            return rc;
+        if (e != hipSuccess)
+            return fail(RTMI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphDestroy(graph));
+        it = h->graphs.emplace(ks, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, h->stream));
+    return RTMI_OK;
+}
+
+int finish(rtmi_pt *h)
+{
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int st = rtmi_device_status())
+        return device_fault(st);
+    return RTMI_OK;
+}
+
+// after a synchronise: the exact maximum of k, so that the next sweeps launch no more slots than needed
+int refresh_kbound(rtmi_pt *h)
+{
+    std::vector<int> k((size_t)h->nchains);
+    HIP_TRY(hipMemcpy(k.data(), h->d.k, k.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int m = 1;
+    for (int v : k)
+        m = v > m ? v : m;
+    h->kbound = m;
+    return RTMI_OK;
+}
+
+int enqueue_swap(rtmi_pt *h)
+{
+    if (!h->d_level)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: no ladder (call rtmi_pt_set_ladder first)");
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(64), 0, h->stream, h->nct, h->first, h->nchains, h->d_logl_all,
+                       h->d_level, h->d_beta_of_level, h->d.seed, h->round, h->d_order, h->d_swstats, h->d.beta);
+    ++h->round;
+    HIP_TRY(hipGetLastError());
+    return RTMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_prior *prior, uint64_t seed,
+                        uint64_t stream_id)
+{
+    if (nchains < 1 || nchains > 65535 || ld_model < 2 || ld_model - 1 > RTMI_MAX_LAYERS || !prior || ndata < 1 ||
+        prior->kmax + 1 > ld_model || prior->kmin < 1 || prior->kmin > prior->kmax || prior->kmax > RTMI_PT_MAX_K) {
+        fail(RTMI_ERR_BAD_ARG, "rtmi_pt_create: bad arguments (1 <= kmin <= kmax <= %d, ld_model >= kmax + 1)",
+             RTMI_PT_MAX_K);
+        return nullptr;
+    }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.ready || c.set_n < 1 || !c.set_has_obs) {
+        fail(RTMI_ERR_BAD_ARG, "rtmi_pt_create: call rtmi_set_sources with observations first");
+        return nullptr;
+    }
+    if (ndata != c.set_n) {
+        fail(RTMI_ERR_BAD_ARG, "rtmi_pt_create: ndata = %lld but the resident source set holds %lld observations",
+             (long long)ndata, (long long)c.set_n);
+        return nullptr;
+    }
+    if (hipSetDevice(c.device) != hipSuccess)
+        return nullptr;
+    rtmi_pt *h = new rtmi_pt;
+    h->device = c.device;
+    h->cus = c.cus;
+    h->nchains = nchains;
+    h->K = prior->kmax;
+    h->ld_model = ld_model;
+    h->max_nl = prior->kmax > 1 ? prior->kmax - 1 : 1;
+    h->nsrc = c.set_n;
+    if (const char *e = getenv("RTMI_PT_GRAPH"))
+        h->use_graph = strcmp(e, "0") != 0;
+    const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n;
+    const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
+    const size_t nf64 = 4 * nc * K + 5 * nc + 2 * nc * ldm;
+    const size_t ni32 = 4 * nc;
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&h->d_set, 3 * n * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_f64, nf64 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_i32, ni32 * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_u64, 9 * nc * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void **)&h->d_partial, nc * (size_t)gx * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_logpk, ((size_t)prior->kmax + 2) * sizeof(double)) == hipSuccess;
+    if (ok) {
+        // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
+        ok = hipMemcpyAsync(h->d_set, c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_f64, 0, nf64 * sizeof(double), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_i32, 0, ni32 * sizeof(int), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_u64, 0, 9 * nc * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_partial, 0, nc * (size_t)gx * sizeof(double), h->stream) == hipSuccess;
+    }
+    std::vector<double> lpk((size_t)prior->kmax + 2, 0.0);
+    for (int k = 1; k <= prior->kmax + 1; ++k)
+        lpk[(size_t)k] = R::log_pk(*prior, k);
+    lpk[0] = lpk[1];
+    if (ok)
+        ok = hipMemcpyAsync(h->d_logpk, lpk.data(), lpk.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) ==
+             hipSuccess;
+    PtDev &d = h->d;
+    memset(&d, 0, sizeof d);
+    d.nchains = nchains;
+    d.K = h->K;
+    d.ld_model = ld_model;
+    d.gx = gx;
+    d.ndata = ndata;
+    d.pr = *prior;
+    d.seed = seed;
+    d.stream_id = (uint32_t)stream_id;
+    d.logpk = h->d_logpk;
+    if (ok) {
+        double *f = h->d_f64;
+        d.z = f, f += nc * K;
+        d.v = f, f += nc * K;
+        d.pz = f, f += nc * K;
+        d.pv = f, f += nc * K;
+        d.sd = f, f += nc;
+        d.logL = f, f += nc;
+        d.ss = f, f += nc;
+        d.beta = f, f += nc;
+        d.plp = f, f += nc;
+        d.V = f, f += nc * ldm;
+        d.D = f, f += nc * ldm;
+        int *i = h->d_i32;
+        d.k = i, i += nc;
+        d.pk = i, i += nc;
+        d.pactive = i, i += nc;
+        d.NL = (int32_t *)i;
+        d.ctr = h->d_u64;
+        d.stats = (long long *)(h->d_u64 + nc);
+        d.partial = h->d_partial;
+        // every chain starts as a half-space at the middle of the velocity prior, sigma 0.01, beta 1 (as the host
+        // engine of round 1 did); rtmi_pt_set_chain overrides
+        std::vector<double> init(nc * K, 0.0), sd0(nc, 0.01), b0(nc, 1.0);
+        std::vector<int> k0(nc, 1);
+        for (size_t q = 0; q < nc; ++q)
+            init[q * K] = 0.5 * (prior->vmin + prior->vmax);
+        ok = hipMemcpyAsync(d.v, init.data(), nc * K * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipMemcpyAsync(d.sd, sd0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipMemcpyAsync(d.beta, b0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipMemcpyAsync(d.k, k0.data(), nc * sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipStreamSynchronize(h->stream) == hipSuccess;
+    }
+    if (!ok) {
+        fail(RTMI_ERR_HIP, "rtmi_pt_create: device allocation or initialisation failed (%s)",
+             hipGetErrorString(hipGetLastError()));
+        rtmi_pt_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void rtmi_pt_destroy(rtmi_pt *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    for (auto &g : h->graphs)
+        (void)hipGraphExecDestroy(g.second);
+    void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val};
+    for (void *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const double *vels, double sd, double beta)
+{
+    if (!h || chain < 0 || chain >= h->nchains || k < 1 || k > h->K || !depths || !vels)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_chain: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t c = (size_t)chain, K = (size_t)h->K;
+    HIP_TRY(hipMemcpyAsync(h->d.z + c * K, depths, (size_t)k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d.v + c * K, vels, (size_t)k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d.sd + c, &sd, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d.beta + c, &beta, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d.k + c, &k, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (k > h->kbound)
+        h->kbound = k;
+    return RTMI_OK;
+}
+
+int rtmi_pt_set_beta(rtmi_pt *h, const double *beta)
+{
+    if (!h || !beta)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_beta: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d.beta, beta, (size_t)h->nchains * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RTMI_OK;
+}
+
+int rtmi_pt_get_all(rtmi_pt *h, int *k, double *depths, double *vels, double *sd, double *logL, double *ss, double *beta)
+{
+    if (!h)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_get_all: NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nc = (size_t)h->nchains, K = (size_t)h->K;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (k)
+        HIP_TRY(hipMemcpy(k, h->d.k, nc * sizeof(int), hipMemcpyDeviceToHost));
+    if (depths)
+        HIP_TRY(hipMemcpy(depths, h->d.z, nc * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (vels)
+        HIP_TRY(hipMemcpy(vels, h->d.v, nc * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (sd)
+        HIP_TRY(hipMemcpy(sd, h->d.sd, nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (logL)
+        HIP_TRY(hipMemcpy(logL, h->d.logL, nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (ss)
+        HIP_TRY(hipMemcpy(ss, h->d.ss, nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (beta)
+        HIP_TRY(hipMemcpy(beta, h->d.beta, nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (int st = rtmi_device_status())
+        return device_fault(st);
+    return RTMI_OK;
+}
+
+int rtmi_pt_get_chain(const rtmi_pt *hc, int chain, int *k, double *depths, double *vels, double *sd, double *logL,
+                      double *ss)
+{
+    rtmi_pt *h = const_cast<rtmi_pt *>(hc);
+    if (!h || chain < 0 || chain >= h->nchains)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_get_chain: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t c = (size_t)chain, K = (size_t)h->K;
+    int kk = 0;
+    HIP_TRY(hipMemcpy(&kk, h->d.k + c, sizeof(int), hipMemcpyDeviceToHost));
+    if (k)
+        *k = kk;
+    if (depths)
+        HIP_TRY(hipMemcpy(depths, h->d.z + c * K, (size_t)kk * sizeof(double), hipMemcpyDeviceToHost));
+    if (vels)
+        HIP_TRY(hipMemcpy(vels, h->d.v + c * K, (size_t)kk * sizeof(double), hipMemcpyDeviceToHost));
+    if (sd)
+        HIP_TRY(hipMemcpy(sd, h->d.sd + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (logL)
+        HIP_TRY(hipMemcpy(logL, h->d.logL + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (ss)
+        HIP_TRY(hipMemcpy(ss, h->d.ss + c, sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+int rtmi_pt_evaluate(rtmi_pt *h)
+{
+    if (!h)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_evaluate: NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    const dim3 g(blocks_for(h->nchains)), b(64);
+    hipLaunchKernelGGL(pt_pack_current_kernel, g, b, 0, h->stream, h->d);
+    int rc = launch_likelihood(h);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, (int)PT_EVAL, 0, (int)PT_NONE, 0, 0);
+    HIP_TRY(hipGetLastError());
+    h->launches += 1;
+    h->models += h->nchains;
+    rc = finish(h);
+    return rc ? rc : refresh_kbound(h);
+}
+
+int rtmi_pt_sweep(rtmi_pt *h, int nsweeps)
+{
+    return rtmi_pt_run(h, nsweeps, 0, nullptr, 0);
+}
+
+int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int *level, const double *beta_of_level,
+                       int nlevels)
+{
+    if (!h || !level || !beta_of_level || nlevels < 1 || nchains_total < h->nchains || first_chain < 0 ||
+        first_chain + h->nchains > nchains_total)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_ladder: bad argument");
+    for (int i = 0; i < nchains_total; ++i)
+        if (level[i] < 0 || level[i] >= nlevels)
+            return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_ladder: level[%d] = %d outside [0, %d)", i, level[i], nlevels);
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    void *old[] = {h->d_level, h->d_order, h->d_logl_all, h->d_beta_of_level, h->d_swstats};
+    for (void *b : old)
+        if (b)
+            HIP_TRY(hipFree(b));
+    h->d_level = h->d_order = nullptr;
+    h->d_logl_all = h->d_beta_of_level = nullptr;
+    h->d_swstats = nullptr;
+    const size_t nct = (size_t)nchains_total;
+    HIP_TRY(hipMalloc((void **)&h->d_level, nct * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&h->d_order, nct * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&h->d_logl_all, nct * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&h->d_beta_of_level, (size_t)nlevels * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&h->d_swstats, 2 * sizeof(long long)));
+    HIP_TRY(hipMemcpy(h->d_level, level, nct * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_beta_of_level, beta_of_level, (size_t)nlevels * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_swstats, 0, 2 * sizeof(long long)));
+    h->nct = nchains_total;
+    h->first = first_chain;
+    h->nlevels = nlevels;
+    h->round = 0;
+    std::vector<double> b((size_t)h->nchains);
+    for (int c = 0; c < h->nchains; ++c)
+        b[(size_t)c] = beta_of_level[level[first_chain + c]];
+    HIP_TRY(hipMemcpy(h->d.beta, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    return RTMI_OK;
+}
+
+int rtmi_pt_get_ladder(rtmi_pt *h, int *level, int64_t *swap_stats2)
+{
+    if (!h || !h->d_level)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_get_ladder: no ladder");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (level)
+        HIP_TRY(hipMemcpy(level, h->d_level, (size_t)h->nct * sizeof(int), hipMemcpyDeviceToHost));
+    if (swap_stats2) {
+        long long s[2];
+        HIP_TRY(hipMemcpy(s, h->d_swstats, sizeof s, hipMemcpyDeviceToHost));
+        swap_stats2[0] = s[0];
+        swap_stats2[1] = s[1];
+    }
+    return RTMI_OK;
+}
+
+// The exchange with the gather done by the caller (MPI_Allgather, gloo, ...): logl_all[nchains_total] on the host.
+int rtmi_pt_swap_round_host(rtmi_pt *h, const double *logl_all)
+{
+    if (!h || !logl_all)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_swap_round_host: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->d_level)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: no ladder (call rtmi_pt_set_ladder first)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_logl_all, logl_all, (size_t)h->nct * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // logl_all is the caller's (pageable) buffer
+    return enqueue_swap(h);
+}
+
+static int swap_round_locked(rtmi_pt *h, rtmi_comm *comm)
+{
+    const int nranks = comm ? rtmi_comm_size(comm) : 1;
+    if (!h->d_level)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: no ladder (call rtmi_pt_set_ladder first)");
+    if (h->nct != h->nchains * nranks || (comm && h->first != rtmi_comm_rank(comm) * h->nchains))
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_swap_round: the ladder has %d chains, the communicator %d ranks x %d "
+                                      "local chains (rank r owns chains r*n .. r*n+n-1)", h->nct, nranks, h->nchains);
+    if (nranks > 1) {
+        // the ONLY data-path collective of the sampler: nchains doubles per rank, once per swap round
+        const int rc = rtmi_comm_allgather_f64(comm, h->d.logL, h->d_logl_all, h->nchains, h->stream);
+        if (rc)
+            return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->d_logl_all, h->d.logL, (size_t)h->nchains * sizeof(double), hipMemcpyDeviceToDevice,
+                               h->stream));
+    }
+    return enqueue_swap(h);
+}
+
+int rtmi_pt_swap_round(rtmi_pt *h, rtmi_comm *comm)
+{
+    if (!h)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_swap_round: NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    return swap_round_locked(h, comm);
+}
+
+int rtmi_pt_sample_buffer(rtmi_pt *h, int capacity)
+{
+    if (!h || capacity < 0)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_sample_buffer: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    void *old[] = {h->d_s_count, h->d_s_meta, h->d_s_val};
+    for (void *b : old)
+        if (b)
+            HIP_TRY(hipFree(b));
+    h->d_s_count = nullptr;
+    h->d_s_meta = nullptr;
+    h->d_s_val = nullptr;
+    h->s_cap = 0;
+    if (capacity == 0)
+        return RTMI_OK;
+    HIP_TRY(hipMalloc((void **)&h->d_s_count, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&h->d_s_meta, (size_t)capacity * 3 * sizeof(long long)));
+    HIP_TRY(hipMalloc((void **)&h->d_s_val, (size_t)capacity * (2 + 2 * (size_t)h->K) * sizeof(double)));
+    HIP_TRY(hipMemset(h->d_s_count, 0, sizeof(int)));
+    HIP_TRY(hipMemset(h->d_s_val, 0, (size_t)capacity * (2 + 2 * (size_t)h->K) * sizeof(double)));
+    h->s_cap = capacity;
+    return RTMI_OK;
+}
+
+int rtmi_pt_samples(rtmi_pt *h, int max_samples, int64_t *sweep, int *chain, int *k, double *sd, double *logL,
+                    double *depths, double *vels, int *dropped)
+{
+    if (!h || max_samples < 0)
+        return -RTMI_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->d_s_count)
+        return 0;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return -RTMI_ERR_HIP;
+    int cnt = 0;
+    if (hipMemcpy(&cnt, h->d_s_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return -RTMI_ERR_HIP;
+    if (dropped)
+        *dropped = cnt > h->s_cap ? cnt - h->s_cap : 0;
+    int n = cnt < h->s_cap ? cnt : h->s_cap;
+    if (n > max_samples)
+        n = max_samples;
+    const size_t K = (size_t)h->K, w = 2 + 2 * K;
+    std::vector<long long> meta((size_t)n * 3);
+    std::vector<double> val((size_t)n * w);
+    if (n > 0) {
+        if (hipMemcpy(meta.data(), h->d_s_meta, meta.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(val.data(), h->d_s_val, val.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            return -RTMI_ERR_HIP;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (sweep)
+            sweep[i] = meta[(size_t)i * 3];
+        if (chain)
+            chain[i] = (int)meta[(size_t)i * 3 + 1];
+        if (k)
+            k[i] = (int)meta[(size_t)i * 3 + 2];
+        if (sd)
+            sd[i] = val[(size_t)i * w];
+        if (logL)
+            logL[i] = val[(size_t)i * w + 1];
+        if (depths)
+            memcpy(depths + (size_t)i * K, &val[(size_t)i * w + 2], K * sizeof(double));
+        if (vels)
+            memcpy(vels + (size_t)i * K, &val[(size_t)i * w + 2 + K], K * sizeof(double));
+    }
+    if (hipMemset(h->d_s_count, 0, sizeof(int)) != hipSuccess)
+        return -RTMI_ERR_HIP;
+    return n;
+}
+
+int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int record_every)
+{
+    if (!h || nsweeps < 0 || swap_every < 0 || record_every < 0)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    if (record_every > 0 && !h->d_s_count)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: record_every > 0 needs rtmi_pt_sample_buffer first");
+    for (int s = 0; s < nsweeps; ++s) {
+        int rc = sweep_once(h);
+        if (rc)
+            return rc;
+        ++h->sweeps_done;
+        if (swap_every > 0 && h->sweeps_done % swap_every == 0) {
+            rc = swap_round_locked(h, comm);
+            if (rc)
+                return rc;
+        }
+        if (record_every > 0 && (s + 1) % record_every == 0) {  // counted within this call
+            hipLaunchKernelGGL(pt_record_kernel, dim3(blocks_for(h->nchains)), dim3(64), 0, h->stream, h->d,
+                               (const int *)h->d_level, h->first, h->sweeps_done, h->s_cap, h->d_s_count, h->d_s_meta,
+                               h->d_s_val);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    const int rc = finish(h);  // the one synchronisation of the call
+    return rc ? rc : refresh_kbound(h);
+}
+
+int rtmi_pt_stats(const rtmi_pt *hc, int64_t *out8)
+{
+    rtmi_pt *h = const_cast<rtmi_pt *>(hc);
+    if (!h || !out8)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<long long> st((size_t)h->nchains * 8);
+    HIP_TRY(hipMemcpy(st.data(), h->d.stats, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 7; ++j) {
+        long long s = 0;
+        for (int c = 0; c < h->nchains; ++c)
+            s += st[(size_t)c * 8 + j];
+        out8[j < 6 ? j : 7] = s;
+    }
+    out8[6] = h->launches;
+    out8[7] += h->models;  // + the models of rtmi_pt_evaluate
+    return RTMI_OK;
+}
+
+// The pairing and acceptance rule of the exchange as a pure host function (no GPU): what pt_swap_kernel runs on the
+// device.  level[] is updated in place; returns accepted swaps (>= 0) or -RTMI_ERR_BAD_ARG.
+int rtmi_pt_swap_decide(int nchains_total, const double *logl_all, int *level, const double *beta_of_level, int nlevels,
+                        uint64_t seed, uint64_t round, int64_t *proposed)
+{
+    if (nchains_total < 1 || !logl_all || !level || !beta_of_level || nlevels < 1)
+        return -RTMI_ERR_BAD_ARG;
+    for (int i = 0; i < nchains_total; ++i)
+        if (level[i] < 0 || level[i] >= nlevels)
+            return -RTMI_ERR_BAD_ARG;
+    std::vector<int> order((size_t)nchains_total);
+    long long prop = 0;
+    const int acc = R::swap_decide(nchains_total, logl_all, level, beta_of_level, seed, round, order.data(), &prop);
+    if (proposed)
+        *proposed += prop;
+    return acc;
+}
+
+}  // extern "C"

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rtmi_tracerays": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp, _ip]),
     "rtmi_dff7": (None, [_dp, _dp, _ip, _dp, _dp, _ip, _dp]),
     "rtmi_set_sources": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int64]),
+    "rtmi_sources_generation": (ctypes.c_uint64, []),
     "rtmi_loglhood_batch": (ctypes.c_int, [_dp, _dp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, _dp,
                                             _dp, _dp]),
     "rtmi_pt_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_uint64, ctypes.c_uint64]),
@@ -48,14 +49,31 @@ SIGNATURES = {
     "rtmi_pt_set_chain": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]),
     "rtmi_pt_set_beta": (ctypes.c_int, [_vp, _dp]),
     "rtmi_pt_get_chain": (ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, _dp, _dp, _dp]),
+    "rtmi_pt_get_all": (ctypes.c_int, [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _dp]),
     "rtmi_pt_evaluate": (ctypes.c_int, [_vp]),
     "rtmi_pt_sweep": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rtmi_pt_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_set_ladder": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]),
+    "rtmi_pt_get_ladder": (ctypes.c_int, [_vp, _ip, ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_swap_round": (ctypes.c_int, [_vp, _vp]),
+    "rtmi_pt_swap_round_host": (ctypes.c_int, [_vp, _dp]),
+    "rtmi_pt_swap_decide": (ctypes.c_int, [ctypes.c_int, _dp, _ip, _dp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                           ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
+    "rtmi_pt_sample_buffer": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rtmi_pt_samples": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), _ip, _ip, _dp, _dp, _dp, _dp, _ip]),
+    "rtmi_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "rtmi_comm_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "rtmi_comm_destroy": (None, [_vp]),
+    "rtmi_comm_size": (ctypes.c_int, [_vp]),
+    "rtmi_comm_rank": (ctypes.c_int, [_vp]),
+    "rtmi_comm_allgather_f64": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
     "rtmi_init": (ctypes.c_int, [ctypes.c_int]),
     "rtmi_last_error": (ctypes.c_char_p, []),
     "rtmi_version": (ctypes.c_int, []),
     "rtmi_device_cus": (ctypes.c_int, []),
     "rtmi_device_status": (ctypes.c_int, []),
+    "rtmi_clear_device_status": (ctypes.c_int, []),
     "rtmi_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_device_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
@@ -225,18 +243,55 @@ class PtPrior(ctypes.Structure):
                 ("pertsdsdsc", ctypes.c_double)]
 
 
+class Comm:
+    """The RCCL communicator of the temperature exchange (rtmi_comm_*): one rank per GPU.  `bcast(bytes_or_None)`
+    must return rank 0's bytes on every rank (torch.distributed.broadcast_object_list, MPI_Bcast ...)."""
+
+    def __init__(self, nranks: int, rank: int, bcast):
+        self.lib = load_library()
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _check(self.lib.rtmi_comm_unique_id(buf))
+        ident = bcast(bytes(buf.raw) if rank == 0 else None)
+        self.h = self.lib.rtmi_comm_create(int(nranks), int(rank), ctypes.create_string_buffer(ident, 128))
+        if not self.h:
+            raise RtmiError("rtmi_comm_create failed: " + self.lib.rtmi_last_error().decode("utf-8", "replace"))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def close(self):
+        if self.h:
+            self.lib.rtmi_comm_destroy(self.h)
+            self.h = None
+
+
+def swap_decide(logl_all, level, beta_of_level, seed: int, round_: int):
+    """The exchange's pairing + acceptance rule on the host (rtmi_pt_swap_decide; no GPU): returns
+    (new level array, accepted, proposed)."""
+    lib = load_library()
+    ll = _as_f64(logl_all)
+    lev = np.ascontiguousarray(level, dtype=np.int32).copy()
+    b = _as_f64(beta_of_level)
+    prop = ctypes.c_int64(0)
+    acc = lib.rtmi_pt_swap_decide(ll.size, ll.ctypes.data_as(_dp), lev.ctypes.data_as(_ip), b.ctypes.data_as(_dp), b.size,
+                                  int(seed), int(round_), ctypes.byref(prop))
+    if acc < 0:
+        raise RtmiError(f"rtmi_pt_swap_decide: bad arguments ({acc})")
+    return lev, int(acc), int(prop.value)
+
+
 class NativeChains:
-    """The chains of one process inside librtmi.so (rtmi_pt_*): native Metropolis-Hastings sweeps over the resident
-    sources (set_sources with observations first)."""
+    """The chains of one process inside librtmi.so (rtmi_pt_*): Metropolis-Hastings sweeps resident on the GPU over a
+    copy of the resident sources (set_sources with observations first)."""
 
     def __init__(self, nchains, ld, ndata, prior, seed=1, stream_id=0):
         self.lib = load_library()
-        self.n, self.ld = int(nchains), int(ld)
+        self.n, self.ld, self.kmax = int(nchains), int(ld), int(prior.kmax)
         pr = PtPrior(prior.kmin, prior.kmax, prior.lam, prior.hmx, prior.hmin, prior.vmin, prior.vmax, prior.sdmin,
                      prior.sdmax, prior.pertsdsc, prior.pertsdsdsc)
         self.h = self.lib.rtmi_pt_create(self.n, self.ld, int(ndata), ctypes.byref(pr), int(seed), int(stream_id))
         if not self.h:
-            raise RtmiError("rtmi_pt_create: bad arguments")
+            raise RtmiError("rtmi_pt_create: " + self.lib.rtmi_last_error().decode("utf-8", "replace"))
+        self.nct = self.n
 
     def close(self):
         if self.h:
@@ -260,18 +315,26 @@ class NativeChains:
 
     def get_chain(self, i):
         k = ctypes.c_int()
-        z, v = np.empty(self.ld), np.empty(self.ld)
+        z, v = np.empty(self.kmax), np.empty(self.kmax)
         sd, ll, ss = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         _check(self.lib.rtmi_pt_get_chain(self.h, i, ctypes.byref(k), z.ctypes.data_as(_dp), v.ctypes.data_as(_dp),
                                           ctypes.byref(sd), ctypes.byref(ll), ctypes.byref(ss)))
         return np.column_stack([z[:k.value], v[:k.value]]), sd.value, ll.value, ss.value
 
+    def get_all(self):
+        """Every chain in one read-back: dict of k [n], z/v [n, kmax], sd, logL, ss, beta [n]."""
+        n, K = self.n, self.kmax
+        k = np.empty(n, np.int32)
+        z, v = np.empty((n, K)), np.empty((n, K))
+        sd, ll, ss, beta = np.empty(n), np.empty(n), np.empty(n), np.empty(n)
+        _check(self.lib.rtmi_pt_get_all(self.h, k.ctypes.data_as(_ip), z.ctypes.data_as(_dp), v.ctypes.data_as(_dp),
+                                        sd.ctypes.data_as(_dp), ll.ctypes.data_as(_dp), ss.ctypes.data_as(_dp),
+                                        beta.ctypes.data_as(_dp)))
+        return {"k": k, "z": z, "v": v, "sd": sd, "logL": ll, "ss": ss, "beta": beta}
+
     def logl(self):
-        ll = ctypes.c_double()
         out = np.empty(self.n)
-        for i in range(self.n):
-            _check(self.lib.rtmi_pt_get_chain(self.h, i, None, None, None, None, ctypes.byref(ll), None))
-            out[i] = ll.value
+        _check(self.lib.rtmi_pt_get_all(self.h, None, None, None, None, out.ctypes.data_as(_dp), None, None))
         return out
 
     def evaluate(self):
@@ -279,6 +342,51 @@ class NativeChains:
 
     def sweep(self, nsweeps=1):
         _check(self.lib.rtmi_pt_sweep(self.h, int(nsweeps)))
+
+    def run(self, nsweeps, swap_every=0, comm=None, record_every=0):
+        """nsweeps sweeps (+ swap rounds, + T = 1 samples into the ring) enqueued without host synchronisation."""
+        _check(self.lib.rtmi_pt_run(self.h, int(nsweeps), int(swap_every), comm.h if comm is not None else None,
+                                    int(record_every)))
+
+    def set_ladder(self, nchains_total, first_chain, level, beta_of_level):
+        lev = np.ascontiguousarray(level, dtype=np.int32)
+        b = _as_f64(beta_of_level)
+        _check(self.lib.rtmi_pt_set_ladder(self.h, int(nchains_total), int(first_chain), lev.ctypes.data_as(_ip),
+                                           b.ctypes.data_as(_dp), b.size))
+        self.nct = int(nchains_total)
+
+    def get_ladder(self):
+        lev = np.empty(self.nct, np.int32)
+        st = (ctypes.c_int64 * 2)()
+        _check(self.lib.rtmi_pt_get_ladder(self.h, lev.ctypes.data_as(_ip), st))
+        return lev, int(st[0]), int(st[1])
+
+    def swap_round(self, comm=None):
+        _check(self.lib.rtmi_pt_swap_round(self.h, comm.h if comm is not None else None))
+
+    def swap_round_host(self, logl_all):
+        ll = _as_f64(logl_all, self.nct, "logl_all")
+        _check(self.lib.rtmi_pt_swap_round_host(self.h, ll.ctypes.data_as(_dp)))
+
+    def sample_buffer(self, capacity):
+        _check(self.lib.rtmi_pt_sample_buffer(self.h, int(capacity)))
+        self._cap = int(capacity)
+
+    def samples(self):
+        """Drains the T = 1 sample ring: dict of sweep, chain, k, sd, logL [m], z / v [m, kmax], dropped."""
+        cap, K = getattr(self, "_cap", 0), self.kmax
+        sweep, chain, k = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+        sd, ll = np.empty(cap), np.empty(cap)
+        z, v = np.empty((cap, K)), np.empty((cap, K))
+        dropped = ctypes.c_int(0)
+        m = self.lib.rtmi_pt_samples(self.h, cap, sweep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                     chain.ctypes.data_as(_ip), k.ctypes.data_as(_ip), sd.ctypes.data_as(_dp),
+                                     ll.ctypes.data_as(_dp), z.ctypes.data_as(_dp), v.ctypes.data_as(_dp),
+                                     ctypes.byref(dropped))
+        if m < 0:
+            _check(-m)
+        return {"sweep": sweep[:m], "chain": chain[:m], "k": k[:m], "sd": sd[:m], "logL": ll[:m], "z": z[:m], "v": v[:m],
+                "dropped": int(dropped.value)}
 
     def stats(self):
         out = (ctypes.c_int64 * 8)()

@@ -110,16 +110,23 @@ class GpuEvaluator:
         self.raymod, self.ld = raymod, ld
         self.n = int(np.asarray(src_offset).size)
         raymod.set_sources(src_offset, src_depth, obs)
+        self.generation = raymod.load_library().rtmi_sources_generation()
         self.launches = 0
         self.models = 0
 
     def set_observations(self, src_offset, src_depth, obs):
         self.raymod.set_sources(src_offset, src_depth, obs)
+        self.generation = self.raymod.load_library().rtmi_sources_generation()
+        self.n = int(np.asarray(src_offset).size)
 
     def __call__(self, node_sets: List[np.ndarray]) -> np.ndarray:
         nm = len(node_sets)
         if nm == 0:
             return np.zeros(0)
+        if self.raymod.load_library().rtmi_sources_generation() != self.generation:
+            # the resident set is ONE per process (like READDATA's module data): somebody replaced it under this evaluator
+            raise RuntimeError("the resident source set was replaced by another rtmi_set_sources call: this evaluator's "
+                               "sources are no longer on the GPU")
         V = np.zeros((nm, self.ld))
         D = np.zeros((nm, self.ld))
         NL = np.zeros(nm, np.int32)
@@ -312,19 +319,29 @@ class Sampler:
 
 
 class NativeSampler(Sampler):
-    """Sampler whose sweeps run inside librtmi.so (rtmi_pt_sweep, csrc/rtmi_pt.cpp): same rules, compiled host code
-    and pinned staging instead of per-chain Python -- the per-slot cost drops from ~0.6 ms to the launch itself.  The
-    temperature exchange and the sample bookkeeping stay here.  `evaluator` must be a GpuEvaluator (it owns the
-    resident sources); proposals use one native random stream per chain."""
+    """Sampler whose sweeps, temperature exchange and sample bookkeeping run on the GPU inside librtmi.so
+    (rtmi_pt_run, csrc/rtmi_pt.hip): chain states never leave HBM between read-outs.  `evaluator` must be a
+    GpuEvaluator (it uploads the sources the handle then copies); proposals use one counter-based random stream per
+    chain.  The exchange is one RCCL all-gather per round when a communicator is given (`comm`), the library's own
+    single-process path when every chain is local, or -- rehearsal of N ranks on fewer GPUs, gloo -- a host gather
+    handed to rtmi_pt_swap_round_host; the decisions are the same function in all three."""
+
+    comm: object = None
 
     def __post_init__(self):
         super().__post_init__()
         from . import raymod
+        self.raymod = raymod
         self.native = raymod.NativeChains(self.nloc, self.evaluator.ld, self.ndata, self.prior, seed=self.seed,
                                           stream_id=self.rank)
-
-    def _push_betas(self):
-        self.native.set_beta([self.beta(i) for i in range(self.nloc)])
+        self.native.set_ladder(self.nchains_total, self.first, self.level, self.beta_of_level)
+        self.comm = None
+        if self.world > 1 and self.dist is not None and self.dist.get_backend() == "nccl":
+            def bcast(b):
+                obj = [b]
+                self.dist.broadcast_object_list(obj, src=0)
+                return obj[0]
+            self.comm = raymod.Comm(self.world, self.rank, bcast)
 
     def _evaluate_current(self):
         for i, c in enumerate(self.chains):
@@ -333,26 +350,67 @@ class NativeSampler(Sampler):
         self._pull(range(self.nloc))
 
     def _pull(self, which):
+        a = self.native.get_all()
         for i in which:
-            nodes, sd, ll, ss = self.native.get_chain(i)
-            self.chains[i] = Chain(nodes, sd, ll, ss)
+            k = int(a["k"][i])
+            self.chains[i] = Chain(np.column_stack([a["z"][i, :k], a["v"][i, :k]]), float(a["sd"][i]),
+                                   float(a["logL"][i]), float(a["ss"][i]))
 
-    def sweep(self):
-        self.native.sweep(1)
+    def _refresh_stats(self):
         st = self.native.stats()
         for k in ("acc_bd", "prop_bd", "acc_mh", "prop_mh", "acc_sd", "prop_sd"):
             self.stats[k] = st[k]
         self.evaluator.launches, self.evaluator.models = st["launches"], st["models"]
-        # only the T = 1 chains are read back every sweep (they are sampled); logL of all for the swaps
-        ll = self.native.logl()
-        for i, c in enumerate(self.chains):
-            c.logL = float(ll[i])
-        self._pull([i for i in range(self.nloc) if self.level[self.first + i] == 0])
+        lev, acc, prop = self.native.get_ladder()
+        self.level = lev.astype(int)
+        self.stats["acc_swap"], self.stats["prop_swap"] = acc, prop
+
+    def sweep(self):
+        self.native.sweep(1)
 
     def swap_round(self):
-        super().swap_round()
-        self._push_betas()
+        if self.world == 1 or self.comm is not None:
+            self.native.swap_round(self.comm)
+        else:
+            # N ranks rehearsing without RCCL (gloo): the gather is done here, the decision on the device as always
+            self.native.swap_round_host(self.gather_logl())
+
+    def gather_logl(self) -> np.ndarray:
+        local = self.native.logl()
+        if self.dist is None or self.world == 1:
+            return local
+        import torch
+        t_loc = torch.as_tensor(local, dtype=torch.float64)
+        t_all = torch.empty(self.nchains_total, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(t_all, t_loc)
+        return t_all.numpy()
+
+    def run(self, nsweeps: int, swap_every: int = 1, burnin: int = 0, thin: int = 1):
+        """Returns the T = 1 samples of the LOCAL chains: list of (k, nodes sorted by depth, sd, logL).  After
+        `burnin` sweeps the chains at T = 1 are recorded after every `thin`-th sweep, on the device."""
+        device_loop = self.world == 1 or self.comm is not None
+        swap_every = swap_every if self.nchains_total > 1 else 0
+        nrec = max(0, nsweeps - burnin)
+        self.native.sample_buffer(max(1, (nrec // max(1, thin) + 1) * self.nloc))
+        if device_loop:
+            self.native.run(min(burnin, nsweeps), swap_every, self.comm, 0)
+            self.native.run(nrec, swap_every, self.comm, thin)
+        else:
+            for it in range(nsweeps):
+                self.native.run(1, 0, None, 1 if (it >= burnin and (it - burnin + 1) % thin == 0) else 0)
+                if swap_every and (it + 1) % swap_every == 0:
+                    self.swap_round()
+        s = self.native.samples()
+        out = []
+        for i in np.argsort(s["sweep"], kind="stable"):
+            k = int(s["k"][i])
+            nodes = np.column_stack([s["z"][i, :k], s["v"][i, :k]])
+            out.append((k, nodes[np.argsort(nodes[:, 0], kind="stable")], float(s["sd"][i]), float(s["logL"][i])))
+        self._refresh_stats()
+        self._pull(range(self.nloc))
+        return out
 
     def sync(self):
-        """Bring every local chain's state back from the library (after the last sweep)."""
+        """Bring every local chain's state and the counters back from the library."""
+        self._refresh_stats()
         self._pull(range(self.nloc))

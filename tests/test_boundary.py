@@ -201,3 +201,26 @@ def test_bench_gpus_n_exits_nonzero_without_devices():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=3 but --gpus 2" in p.stderr
+
+
+@pytest.mark.skipif(not (os.path.exists("/root/reference/ray_tracing_sampling/loglhood.f90") and
+                         os.path.exists("/opt/rocm/bin/amdflang")),
+                    reason="needs the reference's sampler sources and a Fortran compiler (build container only)")
+def test_reference_loglhood_compiles_unchanged_against_the_shim(tmp_path):
+    """the reference's only caller of TraceRays, ray_tracing_sampling/loglhood.f90 (USE RAYMOD,
+    :42; CALL TraceRays :135,144), compiles UNCHANGED against shim/raymod.f90 -- and its object then asks for the shim's
+    module procedure, which in turn asks for the C ABI.  The sources are compiled where they lie (nothing is copied);
+    tests/fortran/mpi_stub.f90 stands in for `USE MPI` (constants only: this is a compile check, nothing is run)."""
+    ref = "/root/reference/ray_tracing_sampling"
+    fc = "/opt/rocm/bin/amdflang"
+    units = [os.path.join(ROOT, "tests", "fortran", "mpi_stub.f90"), f"{ref}/data_type.f90", f"{ref}/rjmcmc_com.f90",
+             f"{ref}/quicksort.f90", os.path.join(ROOT, "shim", "raymod.f90"), f"{ref}/loglhood.f90"]
+    for u in units:
+        obj = os.path.basename(u) + ".o"
+        p = subprocess.run([fc, "-c", "-w", u, "-o", obj], cwd=tmp_path, capture_output=True, text=True)
+        assert p.returncode == 0, f"{u}:\n{p.stderr[-1500:]}"
+    nm = lambda o: subprocess.run(["nm", o], cwd=tmp_path, capture_output=True, text=True).stdout
+    caller, shim = nm("loglhood.f90.o"), nm("raymod.f90.o")
+    sym = [ln.split()[-1] for ln in caller.splitlines() if "tracerays" in ln.lower()]
+    assert sym and all(f" T {s}" in shim for s in sym), (sym, shim)       # the caller's reference is the shim's definition
+    assert " U rtmi_tracerays" in shim                                     # which forwards to the C ABI

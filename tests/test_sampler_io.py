@@ -109,3 +109,22 @@ def test_imap_mode_and_sampling_from_reference_files(tmp_path, kat, T1):
     r = S.run_from_files(str(d), 100, nchains=4)
     rows = S.read_sample_file(str(d / "test_1_voro_sample.txt"), 10)
     assert len(rows) == 20 and max(x["logL"] for x in rows) > 40.0
+
+
+def test_readers_on_the_references_own_files(kat):
+    """tests/golden/test_1_files/ holds the reference's test_1 input files byte for byte (data files of the reference's
+    example: /root/reference/test_1/{filebase.txt, test_1_parameter.dat, test_1_map.dat}) -- "value ! NAME !! comment"
+    records, two values on the sdmn / sdmx lines, no newline at the end of the parameter file, an 80-token map row.
+    The readers must return exactly the values READPARFILE (read_input.f90:22-57) and the MAP reader
+    (prjmh_temper_rf.f90:152-189) would."""
+    d = os.path.join(GOLDEN, "test_1_files")
+    raw = open(os.path.join(d, "test_1_parameter.dat")).read()
+    assert not raw.endswith("\n") and "!!" in raw and raw.count("\n") == 32    # the layout the readers must survive
+    assert S.read_filebase(d) == "test_1"
+    p = S.read_parameter_file(os.path.join(d, "test_1_parameter.dat"))
+    assert p == TEST_1_PARAMETERS
+    assert len(open(os.path.join(d, "test_1_map.dat")).read().split()) == 80
+    k, nodes, sd = S.read_map_file(os.path.join(d, "test_1_map.dat"), p["NLMX"])
+    m = kat["model"]
+    assert k == 7 and sd == 0.02
+    assert nodes[:, 0].tolist() == [0.0] + m["depths"] and nodes[:, 1].tolist() == m["vels"]

@@ -132,7 +132,7 @@ def test_tempered_run_on_test_1(kat):
 
 @pytest.mark.gpu
 def test_native_sweep_samples_the_prior_at_beta_zero(kat):
-    """rtmi_pt_sweep (csrc/rtmi_pt.cpp) with beta = 0: the likelihood drops out of every acceptance ratio, so k must
+    """rtmi_pt_sweep (csrc/rtmi_pt.hip, sweeps resident on the GPU) with beta = 0: the likelihood drops out of every acceptance ratio, so k must
     follow the truncated Poisson prior -- birth/death/bounds bookkeeping of the native sweep -- while every proposal
     still goes through the GPU likelihood."""
     import raytracerfortran_amd as rt
@@ -228,3 +228,195 @@ def test_chains_sharded_over_two_ranks_native(kat):
         v, z = T.layering(np.array(nd))
         ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v, z, off, dep), sd, stable=True)
         assert abs(ll - ref) <= 1e-9 * max(1.0, abs(ref))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the temperature exchange through the C ABI (rtmi_pt_swap_decide: the function the device kernel runs, on the host)
+# ------------------------------------------------------------------------------------------------------------------
+def test_swap_decide_rules_through_the_c_symbol():
+    """TEMPSWP_MH (prjmh_temper_rf.f90:1329-1357) as librtmi exports it: adjacent levels are paired, alternating
+    parity per round; equal temperatures never swap; the levels stay a permutation; the acceptance frequency of a
+    pair follows min(1, exp((beta2 - beta1)(logL1 - logL2)))."""
+    from raytracerfortran_amd import raymod
+    beta = np.array([1.0, 0.8, 0.5, 0.2])
+    # round 0 pairs (0,1) and (2,3); round 1 pairs (1,2) only
+    lev, acc, prop = raymod.swap_decide([0.0, 100.0, 0.0, 100.0], [0, 1, 2, 3], beta, seed=1, round_=0)
+    assert prop == 2 and acc == 2 and lev.tolist() == [1, 0, 3, 2]      # hotter chain has the better fit: always swap
+    lev, acc, prop = raymod.swap_decide([0.0, 100.0, 0.0, 100.0], [0, 1, 2, 3], beta, seed=1, round_=1)
+    assert prop == 1 and lev.tolist() in ([0, 1, 2, 3], [0, 2, 1, 3])
+    # equal temperatures (NPTCHAINS1 > 1 chains at T = 1) are proposed but never swapped
+    lev, acc, prop = raymod.swap_decide([0.0, 100.0], [0, 0], [1.0], seed=1, round_=0)
+    assert (acc, prop, lev.tolist()) == (0, 1, [0, 0])
+    # acceptance frequency: pair at levels (0, 1), logL1 - logL2 = +2 for the colder chain -> p = exp(-0.2 * 2)
+    hits = 0
+    for r in range(0, 8000, 2):
+        lev, acc, _ = raymod.swap_decide([2.0, 0.0], [0, 1], beta, seed=99, round_=r)
+        hits += acc
+    p = math.exp((0.8 - 1.0) * 2.0)
+    assert abs(hits / 4000 - p) < 0.03, (hits / 4000, p)
+    # levels given as a scrambled permutation: partners are neighbours in LEVEL, wherever the chains live
+    lev, acc, prop = raymod.swap_decide([50.0, 0.0, 0.0, 0.0], [3, 0, 2, 1], beta, seed=5, round_=1)
+    assert prop == 1 and sorted(lev.tolist()) == [0, 1, 2, 3]            # round 1 pairs levels (1, 2): chains 3 and 2
+    assert lev[0] == 3 and lev[1] == 0
+
+
+def _swap_decide_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from raytracerfortran_amd import raymod
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nloc, nct = 4, 4 * world
+    beta = 1.3 ** -np.arange(nct)
+    level = np.arange(nct)
+    rng = np.random.default_rng(100 + rank)  # every rank knows only ITS chains' logL
+    acc_tot = 0
+    for rnd in range(50):
+        local = torch.as_tensor(rng.normal(0.0, 3.0, nloc))
+        allv = torch.empty(nct, dtype=torch.float64)
+        dist.all_gather_into_tensor(allv, local)   # the one collective of a swap round (RCCL on the GPUs)
+        level, acc, _ = raymod.swap_decide(allv.numpy(), level, beta, seed=42, round_=rnd)
+        acc_tot += acc
+    q.put((rank, level.tolist(), acc_tot))
+    dist.destroy_process_group()
+
+
+def test_swap_decide_two_ranks_identical_decisions_gloo():
+    """World size 2 on CPU: after every all-gather both ranks call the C symbol and must hold the same ladder."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 2000
+    procs = [ctx.Process(target=_swap_decide_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, lev0, acc0), (_, lev1, acc1) = res
+    assert lev0 == lev1 and sorted(lev0) == list(range(8)) and acc0 == acc1 > 0
+    assert lev0 != list(range(8))
+
+
+@pytest.mark.gpu
+def test_device_swap_round_equals_the_host_rule(kat):
+    """pt_swap_kernel (device) against rtmi_pt_swap_decide (host) on the same logL: identical ladders round after
+    round, betas of the chains follow their levels; with a one-rank RCCL communicator the all-gather path is the one
+    that runs (ncclAllGather on the handle's stream)."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    rt.set_sources(kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"])
+    pr = T.Prior()
+    n = 12
+    nat = raymod.NativeChains(n, 16, 20, pr, seed=21, stream_id=0)
+    rng = np.random.default_rng(8)
+    for i in range(n):
+        nat.set_chain(i, np.array([[0.0, rng.uniform(2000, 6000)], [rng.uniform(500, 4000), rng.uniform(2000, 6000)]]),
+                      0.02, 1.0)
+    nat.evaluate()
+    beta = 1.25 ** -np.arange(n)
+    level = rng.permutation(n)
+    nat.set_ladder(n, 0, level, beta)
+    comm = raymod.Comm(1, 0, lambda b: b)
+    ll = nat.logl()
+    host_level = level.copy()
+    acc_h = prop_h = 0
+    for rnd in range(6):
+        host_level, a, p = raymod.swap_decide(ll, host_level, beta, seed=21, round_=rnd)
+        acc_h, prop_h = acc_h + a, prop_h + p
+        nat.swap_round(comm if rnd % 2 else None)
+    dev_level, acc_d, prop_d = nat.get_ladder()
+    assert dev_level.tolist() == host_level.tolist() and (acc_d, prop_d) == (acc_h, prop_h) and acc_d > 0
+    assert np.array_equal(nat.get_all()["beta"], beta[dev_level])
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_device_run_without_host_synchronisation_and_sample_ring(kat):
+    """rtmi_pt_run: sweeps, swap rounds and the T = 1 sample ring in one call; bookkeeping of every chain against the
+    oracle afterwards; the ring holds exactly one sample per recorded sweep and T = 1 chain."""
+    from oracle import oracle as O
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    m = kat["model"]
+    off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
+    rt.set_sources(off, dep, obs)
+    pr = T.Prior()
+    n = 8
+    nat = raymod.NativeChains(n, 16, 20, pr, seed=3, stream_id=0)
+    nodes = np.column_stack([[0.0] + m["depths"], m["vels"]])
+    for i in range(n):
+        nat.set_chain(i, nodes, 0.02, 1.0)
+    nat.evaluate()
+    assert np.all(np.abs(nat.logl() - kat["test_1_map_logL_survey"]["value"]) < 1e-8)
+    nat.set_ladder(n, 0, [0, 0, 1, 2, 3, 4, 5, 6], 1.4 ** -np.arange(7.0))
+    nat.sample_buffer(2 * 300 + 8)
+    nat.run(100, 1, None, 0)
+    nat.run(300, 1, None, 1)
+    s = nat.samples()
+    assert s["dropped"] == 0 and s["k"].size == 2 * 300
+    assert sorted(set(s["sweep"].tolist())) == list(range(101, 401))
+    assert np.median(s["logL"]) > 30.0
+    a = nat.get_all()
+    lev, acc, prop = nat.get_ladder()
+    assert sorted(lev.tolist()) == [0, 0, 1, 2, 3, 4, 5, 6] and acc > 0
+    assert np.array_equal(a["beta"], (1.4 ** -np.arange(7.0))[lev])
+    for i in range(n):
+        k = int(a["k"][i])
+        c_nodes = np.column_stack([a["z"][i, :k], a["v"][i, :k]])
+        assert T.inside_bounds(c_nodes, pr)
+        v, z = T.layering(c_nodes)
+        t = O.oracle_dff(v, z, off, dep)
+        ref = O.oracle_loglhood_rt(obs, t, a["sd"][i], stable=True)
+        assert abs(a["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref))
+        assert abs(a["ss"][i] - float(np.sum((np.array(obs) - t) ** 2))) <= 1e-9 * max(1e-12, a["ss"][i])
+    st = nat.stats()
+    assert st["acc_bd"] >= 0 and st["acc_mh"] > 0 and st["acc_sd"] > 0 and st["models"] > 0
+
+
+@pytest.mark.gpu
+def test_two_handles_own_their_source_sets(kat):
+    """Two rtmi_pt handles over DIFFERENT data in one process: each keeps its own device copy of the source set, so
+    neither a second rtmi_set_sources nor the other handle retargets it (round 1: one global set, silently shared)."""
+    from oracle import oracle as O
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    m = kat["model"]
+    nodes = np.column_stack([[0.0] + m["depths"], m["vels"]])
+    off1, dep1, obs1 = np.array(kat["test_1_src_offset"]), np.array(kat["test_1_src_depth"]), np.array(kat["test_1_obs_RT"])
+    rng = np.random.default_rng(5)
+    off2, dep2 = rng.uniform(100, 6000, 333), rng.uniform(1100, 4100, 333)
+    obs2 = O.oracle_dff(m["vels"], m["depths"], off2, dep2) + rng.normal(0, 0.02, 333)
+    pr = T.Prior()
+    rt.set_sources(off1, dep1, obs1)
+    g1 = rt.load_library().rtmi_sources_generation()
+    h1 = raymod.NativeChains(4, 16, 20, pr, seed=1)
+    with pytest.raises(raymod.RtmiError, match="ndata"):
+        raymod.NativeChains(4, 16, 333, pr, seed=1)          # ndata must match the resident set
+    ev = T.GpuEvaluator(off2, dep2, obs2)                      # replaces the resident set ...
+    assert rt.load_library().rtmi_sources_generation() == g1 + 1
+    h2 = raymod.NativeChains(4, 16, 333, pr, seed=2)
+    for h in (h1, h2):
+        for i in range(4):
+            h.set_chain(i, nodes, 0.02, 1.0)
+    h1.evaluate()                                              # ... but h1 still evaluates over ITS 20 sources
+    h2.evaluate()
+    ref1 = O.oracle_loglhood_rt(obs1, O.oracle_dff(m["vels"], m["depths"], off1, dep1), 0.02, stable=True)
+    ref2 = O.oracle_loglhood_rt(obs2, O.oracle_dff(m["vels"], m["depths"], off2, dep2), 0.02, stable=True)
+    assert np.all(np.abs(h1.logl() - ref1) <= 1e-11 * abs(ref1))
+    assert np.all(np.abs(h2.logl() - ref2) <= 1e-11 * abs(ref2))
+    h1.sweep(20)
+    h2.sweep(20)
+    for h, (o, z, ob) in ((h1, (off1, dep1, obs1)), (h2, (off2, dep2, obs2))):
+        a = h.get_all()
+        for i in range(4):
+            k = int(a["k"][i])
+            v, d = T.layering(np.column_stack([a["z"][i, :k], a["v"][i, :k]]))
+            ref = O.oracle_loglhood_rt(ob, O.oracle_dff(v, d, o, z), a["sd"][i], stable=True)
+            assert abs(a["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref))
+    # an evaluator whose set was replaced by someone else says so instead of computing over the wrong data
+    rt.set_sources(off1, dep1, obs1)
+    with pytest.raises(RuntimeError, match="replaced"):
+        ev([nodes])
