@@ -67,73 +67,94 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
         dst[i] = src[i];
 }
 
+// Per-thread working arrays of the sweep kernels live in LDS, not in private (scratch) memory: the rules index them
+// dynamically (insertion sort of the nodes), and a scratch access costs a trip to HBM -- a one-thread-per-chain kernel
+// is nothing but a chain of such latencies.  Layout: thread t owns [t * stride, (t + 1) * stride).
+#define PT_BLOCK 64
+
 // One thread per chain: [decide the previous slot] [sigma move] [propose the next slot].
-__global__ void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
+__global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
 {
+    extern __shared__ __attribute__((aligned(16))) double pt_lds[];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nchains)
         return;
+    double *qz = pt_lds + (size_t)threadIdx.x * d.K;
+    double *qv = pt_lds + (size_t)PT_BLOCK * d.K + (size_t)threadIdx.x * d.K;
+    int *ord = reinterpret_cast<int *>(pt_lds + (size_t)2 * PT_BLOCK * d.K) + (size_t)threadIdx.x * d.K;
     const rtmi_pt_prior &p = d.pr;
-    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, d.ctr[c]);
+    // everything the thread will need, requested up front (independent loads: one round trip, not a chain of them)
     int k = d.k[c];
+    const int act = d.pactive[c];
+    const int pk = d.pk[c];
+    const unsigned long long ctr0 = d.ctr[c];
+    double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
+    const double beta = d.beta[c], plp = d.plp[c];
     double *zc = d.z + (size_t)c * d.K, *vc = d.v + (size_t)c * d.K;
     double *pz = d.pz + (size_t)c * d.K, *pv = d.pv + (size_t)c * d.K;
     long long *st = d.stats + (size_t)c * 8;
+    double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
+    if (decide != PT_NONE && act != 0)
+        for (int i = 0; i < d.gx; ++i)
+            part = part + d.partial[(size_t)c * d.gx + i];
+    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
 
     // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
-    const int act = d.pactive[c];
+    bool accepted = false;
     if (decide != PT_NONE && act != 0) {
-        double s = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
-        for (int i = 0; i < d.gx; ++i)
-            s = s + d.partial[(size_t)c * d.gx + i];
-        const double logl_new = R::gaussian_loglike(s, d.ndata, d.sd[c]);
+        const double logl_new = R::gaussian_loglike(part, d.ndata, sd);
         if (act == 2) {
-            d.ss[c] = s;
-            d.logL[c] = logl_new;
+            ss = part;
+            logL = logl_new;
         } else {
-            double lr = d.plp[c] + (logl_new - d.logL[c]) * d.beta[c];
+            double lr = plp + (logl_new - logL) * beta;
             if (lr > 50.0)
                 lr = 50.0;
             st[2 * decide + 1] += 1;
             if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
-                k = d.pk[c];
-                d.k[c] = k;
-                load_nodes(pz, zc, k);
-                load_nodes(pv, vc, k);
-                d.ss[c] = s;
-                d.logL[c] = logl_new;
+                accepted = true;
+                k = pk;
+                ss = part;
+                logL = logl_new;
                 st[2 * decide] += 1;
             }
         }
         d.pactive[c] = 0;
+    }
+    // the chain's (possibly just accepted) nodes into the thread's LDS arrays
+    load_nodes(accepted ? pz : zc, qz, k);
+    load_nodes(accepted ? pv : vc, qv, k);
+    if (accepted) {
+        d.k[c] = k;
+        load_nodes(qz, zc, k);
+        load_nodes(qv, vc, k);
     }
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
     if (sigma) {
         if (R::philox_uniform(rng) >= 0.10) {
             const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
-            const double sd_new = d.sd[c] + step * R::philox_normal(rng);
+            const double sd_new = sd + step * R::philox_normal(rng);
             st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
-                const double logl_new = R::gaussian_loglike(d.ss[c], d.ndata, sd_new);
-                double lr = (logl_new - d.logL[c]) * d.beta[c];
+                const double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
+                double lr = (logl_new - logL) * beta;
                 if (lr > 50.0)
                     lr = 50.0;
                 if (!(R::philox_uniform(rng) >= exp(lr))) {
-                    d.sd[c] = sd_new;
-                    d.logL[c] = logl_new;
+                    sd = sd_new;
+                    logL = logl_new;
                     st[4] += 1;
                 }
             }
         }
     }
+    d.sd[c] = sd;
+    d.logL[c] = logL;
+    d.ss[c] = ss;
 
     // ---- proposal of the next slot --------------------------------------------------------------------------------
     if (propose != PT_NONE) {
-        double qz[RTMI_PT_MAX_K], qv[RTMI_PT_MAX_K];
-        int ord[RTMI_PT_MAX_K];
-        load_nodes(zc, qz, k);
-        load_nodes(vc, qv, k);
         int qk = k;
         double lp = 0.0;
         bool have = false;
@@ -197,34 +218,53 @@ __global__ void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int 
 }
 
 // The current state of every chain as batch rows (rtmi_pt_evaluate).
-__global__ void pt_pack_current_kernel(PtDev d)
+__global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
 {
+    extern __shared__ __attribute__((aligned(16))) double pt_lds[];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nchains)
         return;
     const int k = d.k[c];
-    int ord[RTMI_PT_MAX_K];
-    const double *zc = d.z + (size_t)c * d.K, *vc = d.v + (size_t)c * d.K;
-    R::sorted_order(zc, k, ord);
-    d.NL[c] = R::pack_model(zc, vc, k, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
+    double *qz = pt_lds + (size_t)threadIdx.x * d.K;
+    double *qv = pt_lds + (size_t)PT_BLOCK * d.K + (size_t)threadIdx.x * d.K;
+    int *ord = reinterpret_cast<int *>(pt_lds + (size_t)2 * PT_BLOCK * d.K) + (size_t)threadIdx.x * d.K;
+    load_nodes(d.z + (size_t)c * d.K, qz, k);
+    load_nodes(d.v + (size_t)c * d.K, qv, k);
+    R::sorted_order(qz, k, ord);
+    d.NL[c] = R::pack_model(qz, qv, k, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
     d.pactive[c] = 2;
 }
 
-// Temperature exchange: thread 0 runs the shared deterministic pairing over ALL chains (every rank the same), then
-// every thread refreshes the temperature of its local chain.
-__global__ void pt_swap_kernel(int nct, int first, int nloc, const double *logl_all, int *level,
-                               const double *beta_of_level, uint64_t seed, uint64_t round, int *order, long long *swstats,
-                               double *beta)
+// Temperature exchange: logL, levels and the ladder are staged in LDS, thread 0 runs the shared deterministic pairing
+// over ALL chains (every rank the same), then every thread writes the levels back and refreshes the temperature of
+// its local chains.  logl_local != NULL: every chain is local and its logL is read in place (no gather needed).
+__global__ void pt_swap_kernel(int nct, int first, int nloc, const double *logl_all, const double *logl_local, int *level,
+                               const double *beta_of_level, int nlevels, uint64_t seed, uint64_t round,
+                               long long *swstats, double *beta)
 {
+    extern __shared__ __attribute__((aligned(16))) double pt_lds[];
+    double *s_logl = pt_lds;
+    double *s_beta = s_logl + nct;
+    int *s_level = reinterpret_cast<int *>(s_beta + nlevels);
+    int *s_order = s_level + nct;
+    for (int i = threadIdx.x; i < nct; i += blockDim.x) {
+        s_logl[i] = logl_local ? logl_local[i] : logl_all[i];
+        s_level[i] = level[i];
+    }
+    for (int i = threadIdx.x; i < nlevels; i += blockDim.x)
+        s_beta[i] = beta_of_level[i];
+    __syncthreads();
     if (threadIdx.x == 0) {
         long long prop = 0;
-        const int acc = R::swap_decide(nct, logl_all, level, beta_of_level, seed, round, order, &prop);
+        const int acc = R::swap_decide(nct, s_logl, s_level, s_beta, seed, round, s_order, &prop);
         swstats[0] += acc;
         swstats[1] += prop;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < nct; i += blockDim.x)
+        level[i] = s_level[i];
     for (int c = threadIdx.x; c < nloc; c += blockDim.x)
-        beta[c] = beta_of_level[level[first + c]];
+        beta[c] = s_beta[s_level[first + c]];
 }
 
 // Append the chains that are at T = 1 (level 0) to the sample ring: {sweep, chain, k, sd, logL, z[K], v[K]}.
@@ -289,7 +329,8 @@ struct rtmi_pt {
 
 namespace {
 
-int blocks_for(int n) { return (n + 63) / 64; }
+int blocks_for(int n) { return (n + PT_BLOCK - 1) / PT_BLOCK; }
+size_t step_lds(const rtmi_pt *h) { return (size_t)PT_BLOCK * (size_t)h->K * (2 * sizeof(double) + sizeof(int)); }
 
 int launch_likelihood(rtmi_pt *h)
 {
@@ -309,7 +350,7 @@ int launch_likelihood(rtmi_pt *h)
 int enqueue_sweep(rtmi_pt *h, int nslots_k)
 {
     const dim3 g(blocks_for(h->nchains)), b(64);
-    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, (int)PT_NONE, 0, (int)PT_BD, 0, 0);
+    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, (int)PT_NONE, 0, (int)PT_BD, 0, 0);
     int rc = launch_likelihood(h);
     if (rc)
         return rc;
@@ -318,13 +359,13 @@ int enqueue_sweep(rtmi_pt *h, int nslots_k)
         for (int ipar = 0; ipar < 2; ++ipar) {
             if (ivo == 0 && ipar == 0)
                 continue;  // the surface node's depth is not a parameter (:727)
-            hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, prev, 0, (int)PT_MH, ivo, ipar);
+            hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, prev, 0, (int)PT_MH, ivo, ipar);
             rc = launch_likelihood(h);
             if (rc)
                 return rc;
             prev = PT_MH;
         }
-    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, prev, 1, (int)PT_NONE, 0, 0);
+    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, prev, 1, (int)PT_NONE, 0, 0);
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
@@ -379,12 +420,17 @@ int refresh_kbound(rtmi_pt *h)
     return RTMI_OK;
 }
 
-int enqueue_swap(rtmi_pt *h)
+int enqueue_swap(rtmi_pt *h, bool local_logl = false)
 {
     if (!h->d_level)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: no ladder (call rtmi_pt_set_ladder first)");
-    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(64), 0, h->stream, h->nct, h->first, h->nchains, h->d_logl_all,
-                       h->d_level, h->d_beta_of_level, h->d.seed, h->round, h->d_order, h->d_swstats, h->d.beta);
+    const size_t lds = (size_t)h->nct * (sizeof(double) + 2 * sizeof(int)) + (size_t)h->nlevels * sizeof(double) + 16;
+    if (lds > 64 * 1024)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: a ladder of %d chains does not fit the exchange kernel's LDS", h->nct);
+    hipLaunchKernelGGL(pt_swap_kernel, dim3(1), dim3(256), lds, h->stream, h->nct, h->first, h->nchains,
+                       (const double *)h->d_logl_all, local_logl ? (const double *)h->d.logL : (const double *)nullptr,
+                       h->d_level, (const double *)h->d_beta_of_level, h->nlevels, h->d.seed, h->round, h->d_swstats,
+                       h->d.beta);
     ++h->round;
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
@@ -416,6 +462,18 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     }
     if (hipSetDevice(c.device) != hipSuccess)
         return nullptr;
+    {
+        // the sweep kernels keep K doubles x 2 + K ints per thread in LDS: above 64 KiB that needs the opt-in
+        const size_t need = (size_t)PT_BLOCK * (size_t)prior->kmax * (2 * sizeof(double) + sizeof(int));
+        if (need > 64 * 1024 &&
+            (hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)need) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_pack_current_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)) {
+            fail(RTMI_ERR_HIP, "rtmi_pt_create: cannot reserve %zu bytes of LDS for the sweep kernels", need);
+            return nullptr;
+        }
+    }
     rtmi_pt *h = new rtmi_pt;
     h->device = c.device;
     h->cus = c.cus;
@@ -614,11 +672,11 @@ int rtmi_pt_evaluate(rtmi_pt *h)
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     const dim3 g(blocks_for(h->nchains)), b(64);
-    hipLaunchKernelGGL(pt_pack_current_kernel, g, b, 0, h->stream, h->d);
+    hipLaunchKernelGGL(pt_pack_current_kernel, g, b, step_lds(h), h->stream, h->d);
     int rc = launch_likelihood(h);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(pt_step_kernel, g, b, 0, h->stream, h->d, (int)PT_EVAL, 0, (int)PT_NONE, 0, 0);
+    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, (int)PT_EVAL, 0, (int)PT_NONE, 0, 0);
     HIP_TRY(hipGetLastError());
     h->launches += 1;
     h->models += h->nchains;
@@ -715,11 +773,8 @@ static int swap_round_locked(rtmi_pt *h, rtmi_comm *comm)
         const int rc = rtmi_comm_allgather_f64(comm, h->d.logL, h->d_logl_all, h->nchains, h->stream);
         if (rc)
             return rc;
-    } else {
-        HIP_TRY(hipMemcpyAsync(h->d_logl_all, h->d.logL, (size_t)h->nchains * sizeof(double), hipMemcpyDeviceToDevice,
-                               h->stream));
     }
-    return enqueue_swap(h);
+    return enqueue_swap(h, nranks == 1);  // every chain local: logL is read in place
 }
 
 int rtmi_pt_swap_round(rtmi_pt *h, rtmi_comm *comm)
