@@ -289,6 +289,28 @@ int64_t rtmi_trace_batch_work_bytes(int nmodels, int64_t nsrc);
 int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double *d_den, int64_t n,
                            unsigned long long *d_mismatch, void *stream);
 /*
+ * Extended form for the constructed hard cases of tests/test_gpu_fastmath_hard.py: d_mismatch64[0..2] as above,
+ * d_mismatch64[3] += layer-term mismatches counted WITHOUT regard to the term's own guard (the all-ones-divisor test of
+ * what the kernels would return with that guard compiled out), d_mismatch64[4] += operands the
+ * guard rejected (for which the kernels take the plain operators), d_mismatch64[5] += operands that mismatched
+ * (guard ignored), whose first 58 indices are stored in d_mismatch64[6..63] (bit 63 set: the guard had accepted it).  64 x uint64, zeroed by the caller.
+ */
+int rtmi_selftest_fastmath_ex(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                              unsigned long long *d_mismatch64, void *stream);
+/*
+ * The VALUES of the kernels' arithmetic building blocks, for comparison with an IEEE host (the tests use numpy; the
+ * GPU's own `/` is not a valid checker: hipcc's fp64 divide is faithful but not always correctly rounded):
+ *   d_div         num / den as the kernels divide outside their fast forms (compiler's quotient + one repair step)
+ *   d_div_guarded the guarded divide of the fast paths; NaN where its guard rejects the divisor
+ *   d_sqrt        the guarded square root of w
+ *   d_tf, d_tp    the shared-reciprocal layer term num / sqrt(w), den / sqrt(w)^3; NaN where the term's guard rejects
+ * Any output pointer may be NULL.  All device pointers.
+ */
+int rtmi_selftest_values(const double *d_w, const double *d_num, const double *d_den, int64_t n, double *d_div,
+                         double *d_div_guarded, double *d_sqrt, double *d_tf, double *d_tp, void *stream);
+int rtmi_selftest_values_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n, float *d_div,
+                             float *d_tf, float *d_tp, void *stream);
+/*
  * The same for the single-precision layer term (fp32 path): d_mismatch[0] += mismatches of num/sqrtf(w),
  * d_mismatch[1] += mismatches of den/sqrtf(w)^3 (2 x uint64, zeroed by the caller); guarded ranges
  * w in (1e-12, 1], num and den 0 or in (1e-18, 1e18).

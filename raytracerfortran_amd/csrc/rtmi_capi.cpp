@@ -781,7 +781,40 @@ int rtmi_selftest_fastmath(const double *d_w, const double *d_num, const double 
         return fail(RTMI_ERR_BAD_ARG, "bad argument");
     if (n == 0)
         return RTMI_OK;
-    HIP_TRY(rtmi_launch_fastmath_check(d_w, d_num, d_den, n, d_mismatch, (hipStream_t)stream));
+    HIP_TRY(rtmi_launch_fastmath_check(d_w, d_num, d_den, n, d_mismatch, 0, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+int rtmi_selftest_fastmath_ex(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                              unsigned long long *d_mismatch5, void *stream)
+{
+    if (n < 0 || !d_w || !d_num || !d_den || !d_mismatch5)
+        return fail(RTMI_ERR_BAD_ARG, "bad argument");
+    if (n == 0)
+        return RTMI_OK;
+    HIP_TRY(rtmi_launch_fastmath_check(d_w, d_num, d_den, n, d_mismatch5, 1, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+int rtmi_selftest_values(const double *d_w, const double *d_num, const double *d_den, int64_t n, double *d_div,
+                         double *d_div_guarded, double *d_sqrt, double *d_tf, double *d_tp, void *stream)
+{
+    if (n < 0 || !d_w || !d_num || !d_den)
+        return fail(RTMI_ERR_BAD_ARG, "bad argument");
+    if (n == 0)
+        return RTMI_OK;
+    HIP_TRY(rtmi_launch_fastmath_values(d_w, d_num, d_den, n, d_div, d_div_guarded, d_sqrt, d_tf, d_tp, (hipStream_t)stream));
+    return RTMI_OK;
+}
+
+int rtmi_selftest_values_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n, float *d_div,
+                             float *d_tf, float *d_tp, void *stream)
+{
+    if (n < 0 || !d_w || !d_num || !d_den)
+        return fail(RTMI_ERR_BAD_ARG, "bad argument");
+    if (n == 0)
+        return RTMI_OK;
+    HIP_TRY(rtmi_launch_fastmath_values_f32(d_w, d_num, d_den, n, d_div, d_tf, d_tp, (hipStream_t)stream));
     return RTMI_OK;
 }
 

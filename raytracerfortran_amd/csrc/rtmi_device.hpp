@@ -91,6 +91,10 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool r
     return t;
 }
 
+// the IEEE divide of the kernels (defined below, next to the guarded fast forms)
+__device__ __forceinline__ double div_ieee(double n, double d);
+__device__ __forceinline__ float div_ieee(float n, float d);
+
 // v == 0 or |v| inside (1e-30, 1e30): safe as one factor of a numerator of div_guarded (the product of two
 // such factors stays far from the exponent ranges where v_div_scale / v_div_fixup would act).
 __device__ __forceinline__ bool mag_ok(float v)  // single precision: the same idea over a narrower exponent range
@@ -144,7 +148,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             t.D[i] = d;
             t.H[i] = h;
             t.HV[i] = h * v;
-            t.Q[i] = h / v;
+            t.Q[i] = div_ieee(h, v);
             t.HW[i].hv = h * v;
             t.HW[i].vv = v * v;
         }
@@ -222,7 +226,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         }
     }
     for (int i = threadIdx.x; i <= nlayers; i += blockDim.x)
-        t.VMI[i] = T(1.0) / t.VMAX[i];
+        t.VMI[i] = div_ieee(T(1.0), t.VMAX[i]);
     if constexpr (WITH_HINT) {
         // Where the fused kernel's solve order comes from (trip_class): a ray that needs many evaluations is one
         // that runs almost horizontally in the fastest layer j of its stack (p close to 1/vmax).  There the
@@ -362,23 +366,66 @@ __device__ __forceinline__ double sqrt_guarded(double w)  // w in (1e-60, 1e60)
     return g;
 }
 
-__device__ __forceinline__ double div_guarded(double n, double d)  // d in (1e-90, 1e30), n == 0 or |n| in (1e-60, 1e60)
+// ---------------------------------------------------------------------------------------------
+// The IEEE divide.  hipcc's expansion of `n / d` (v_rcp + two Newton steps + one residual correction + scale/fixup)
+// is FAITHFUL but not always correctly rounded on gfx950: for a divisor a few ulps below a power of two (mantissa
+// 2^53 - M, M = 5, 11, 13 ... observed) the refined reciprocal lands on the wrong side of a rounding midpoint
+// (Markstein's exception, widened by the error the refinement starts from), and quotients that sit next to a
+// midpoint themselves come out one ulp off -- e.g. 0x1.6666666666663p-130 / 0x1.ffffffffffffbp-62 returns
+// ...666p-69 where IEEE 754 (and the reference's x86 divide) gives ...667p-69 (tests/hardcases.py builds such
+// operands; profiles/r02c/gpu_div_vs_cpu.txt).  One wrong ulp flips a solver branch, so every division the kernels
+// perform outside their guarded fast forms goes through div_ieee: the compiler's quotient plus ONE repair step --
+// the exact remainders of q and of its neighbour on the remainder's side decide which of the two is the correctly
+// rounded quotient (a faithful q is at most one ulp off, and n - d*q of a faithful q is exactly representable).
+// Operands outside the comfortable exponent range (tiny n, sub-normal q, Inf, NaN) keep the compiler's result.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double div_ieee(double n, double d)
+{
+    const double q = n / d;
+    const double rem = __builtin_fma(-d, q, n);
+    const bool up = (rem > 0.0) == (d > 0.0);                        // the exact quotient lies above q
+    const long long step = (up == (q > 0.0)) ? 1ll : -1ll;            // ... i.e. one ulp further from / closer to zero
+    const double qa = __longlong_as_double(__double_as_longlong(q) + step);
+    const double rema = __builtin_fma(-d, qa, n);
+    const bool safe = fabs(n) > 1e-200 && fabs(q) > 1e-290 && fabs(q) < 1e300;
+    return (safe && fabs(rema) < fabs(rem)) ? qa : q;
+}
+__device__ __forceinline__ float div_ieee(float n, float d)
+{
+    const float q = n / d;
+    const float rem = __builtin_fmaf(-d, q, n);
+    const bool up = (rem > 0.0f) == (d > 0.0f);
+    const int step = (up == (q > 0.0f)) ? 1 : -1;
+    const float qa = __int_as_float(__float_as_int(q) + step);
+    const float rema = __builtin_fmaf(-d, qa, n);
+    const bool safe = fabsf(n) > 1e-20f && fabsf(q) > 1e-30f && fabsf(q) < 1e30f;
+    return (safe && fabsf(rema) < fabsf(rem)) ? qa : q;
+}
+
+// n / d for d in (1e-90, 1e30), n == 0 or |n| in (1e-60, 1e60): v_rcp_f64 refined by THREE Newton steps is the
+// correctly rounded reciprocal (the third step starts from within an ulp, whatever the accuracy of v_rcp_f64) for
+// every divisor but the all-ones mantissa, so the residual correction returns the correctly rounded quotient
+// (Markstein 1990).  `ok` is cleared for a divisor whose low mantissa word is all ones (the caller then takes div_ieee).
+__device__ __forceinline__ double div_guarded(double n, double d, bool &ok)
 {
     double r = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
     const double q = n * r;
     const double res = __builtin_fma(-d, q, n);
+    ok = ok && (uint32_t)__double2loint(d) != 0xFFFFFFFFu;
     return __builtin_fma(res, r, q);
 }
 
 // One layer term of costFunc and costFunc_Prime with a shared reciprocal:  tf = a / s,  tp = hv / ((s*s)*s),
-// s = sqrt(w).  The square-root iteration already carries h ~ 1/(2s); 2h refined by one Newton step against
-// the final s is the correctly rounded reciprocal r of s (Markstein 1990), which serves the first quotient
-// directly and -- cubed, then refined once against the ROUNDED cube s3 the reference divides by -- the
-// second.  Each quotient ends with the same residual correction q' = fma(fma(-d, q, n), r, q) as the plain
+// s = sqrt(w).  The square-root iteration already carries h ~ 1/(2s); 2h refined by TWO Newton steps against
+// the final s is the correctly rounded reciprocal r of s (Markstein 1990; one step is not enough, see below), which
+// serves the first quotient directly and -- cubed, then refined once against the ROUNDED cube s3 the reference
+// divides by -- the second.  Each quotient ends with the same residual correction q' = fma(fma(-d, q, n), r, q) as the plain
 // divide, which returns the correctly rounded n/d when r is the correctly rounded reciprocal.  The one family
 // of divisors for which a refined reciprocal is NOT correctly rounded is the all-ones mantissa (the refinement
 // lands exactly on a rounding tie); there, quotients of "short" numerators (powers of two, small integers) come
@@ -420,6 +467,16 @@ __device__ __forceinline__ bool term_guarded_n(const double (&w)[N], const doubl
     RTMI_EACH g[j] = __builtin_fma(d[j], h[j], g[j]);
 #pragma unroll
     RTMI_EACH r[j] = h[j] + h[j];
+    // two Newton steps: 2h carries the error of the coupled iteration (measured: up to ~13 units of 2^-53; the ISA
+    // only promises v_rsq_f64 to ~2^-23, i.e. up to ~190 such units after one coupled step), and ONE step from k
+    // units rounds 1/s to the wrong neighbour whenever the mantissa of s lies within k of all-ones (1/s then sits
+    // k^2 2^-106 below ... M^2 2^-106 above a rounding midpoint, M = 2^53 - mantissa) -- which the first evaluation
+    // of every bisection (x1 = 1e-10: s = 1 - M 2^-53 with M ~ 5e-5 v^2) meets systematically for slow layers.  The
+    // second step starts from within one ulp and leaves exactly Markstein's exception, M = 1, to the guard below.
+#pragma unroll
+    RTMI_EACH e[j] = __builtin_fma(-g[j], r[j], 1.0);
+#pragma unroll
+    RTMI_EACH r[j] = __builtin_fma(r[j], e[j], r[j]);
 #pragma unroll
     RTMI_EACH e[j] = __builtin_fma(-g[j], r[j], 1.0);
 #pragma unroll
@@ -430,6 +487,8 @@ __device__ __forceinline__ bool term_guarded_n(const double (&w)[N], const doubl
     RTMI_EACH tf[j] = __builtin_fma(__builtin_fma(-g[j], q[j], a[j]), r[j], q[j]);
 #pragma unroll
     RTMI_EACH s3[j] = (g[j] * g[j]) * g[j];
+    // r correctly rounded => (r*r)*r is within 7 units of 2^-53 of 1/s3 (three factors, two roundings, two more in s3):
+    // one Newton step rounds 1/s3 correctly unless the mantissa of s3 lies within 7 of all-ones -- the guard below.
 #pragma unroll
     RTMI_EACH r3[j] = (r[j] * r[j]) * r[j];
 #pragma unroll
@@ -440,12 +499,17 @@ __device__ __forceinline__ bool term_guarded_n(const double (&w)[N], const doubl
     RTMI_EACH q[j] = hv[j] * r3[j];
 #pragma unroll
     RTMI_EACH tp[j] = __builtin_fma(__builtin_fma(-s3[j], q[j], hv[j]), r3[j], q[j]);
-    // no divisor with an all-ones low mantissa word (see above): one compare on the maximum of the low words
-    uint32_t mx = 0;
+    // the guard: no s with an all-ones low mantissa word, no s3 whose low word is within 7 of all-ones (necessary
+    // conditions of the two exceptions above; one ordinary operand in 2^29 trips them): two integer maxima per group
+    uint32_t mx = 0, mx3 = 0;
 #pragma unroll
-    RTMI_EACH mx = max(mx, max((uint32_t)__double2loint(g[j]), (uint32_t)__double2loint(s3[j])));
+    RTMI_EACH
+    {
+        mx = max(mx, (uint32_t)__double2loint(g[j]));
+        mx3 = max(mx3, (uint32_t)__double2loint(s3[j]));
+    }
 #undef RTMI_EACH
-    return mx != 0xFFFFFFFFu;
+    return mx != 0xFFFFFFFFu && mx3 < 0xFFFFFFF8u;
 }
 
 // The single-precision form of term_guarded_n: v_rsq_f32 is good to an ulp, so one coupled iteration and one
@@ -541,8 +605,8 @@ __device__ __forceinline__ bool layer_term(T xx, T x, T hv, T vv, T &tf, T &tp)
         return sound && w > guard_w<T>();
     } else {
         const T s = sqrt(w);
-        tf = (hv * x) / s;
-        tp = hv / ((s * s) * s);
+        tf = div_ieee(T(hv * x), s);
+        tp = div_ieee(hv, T((s * s) * s));
         return true;
     }
 }
@@ -656,6 +720,21 @@ __device__ __forceinline__ void eval_f_fp(const LayerTable<T> &t, T x, int nfull
         eval_terms<false, false>(t, x, nfull, nfull_wave, hvl, vvl, R, f, fp);
 }
 
+// f / f' of the state machine (cf/cfp of GetPTime :138, deltax of solvebst :384 and of solve :294): the guarded divide
+// when every live lane's operands are inside its range (f 0 or of moderate magnitude, f' of moderate magnitude and
+// not an all-ones mantissa), the repaired IEEE divide for the whole wave otherwise.  Every lane of the wave calls it.
+template <typename T>
+__device__ __forceinline__ T solver_quotient(T f, T fp, bool busy)
+{
+    if constexpr (std::is_same<T, double>::value) {
+        bool ok = mag_ok(f) && mag_nz(fp);
+        const T q = div_guarded(f, fp, ok);
+        if (!__any(busy && !ok))
+            return q;
+    }
+    return div_ieee(f, fp);
+}
+
 // Solver state of one source (one lane).
 template <typename T>
 struct Lane {
@@ -704,17 +783,18 @@ __device__ __forceinline__ T initial_p0_impl(const LayerTable<T> &t, int il, T R
     const T rr = R * R + z * z;
     T p0;
     if constexpr (FAST && std::is_same<T, double>::value) {
-        const T tv = t.PS[il - 1] + div_guarded(hl, vl);  // vertical time above the source
-        const T c_harmonic = div_guarded(z, tv);
-        const T cos_t = div_guarded(z, sqrt_guarded(rr));
-        p0 = div_guarded(cos_t, c_harmonic);
+        bool dok = true;  // no divisor with an all-ones low mantissa word
+        const T tv = t.PS[il - 1] + div_guarded(hl, vl, dok);  // vertical time above the source
+        const T c_harmonic = div_guarded(z, tv, dok);
+        const T cos_t = div_guarded(z, sqrt_guarded(rr), dok);
+        p0 = div_guarded(cos_t, c_harmonic, dok);
         // every numerator 0 or of moderate magnitude, every denominator of moderate magnitude
-        ok = mag_ok(hl) && mag_nz(vl) && mag_nz(tv) && mag_nz(z) && rr > 1e-60 && rr < 1e60 && mag_nz(c_harmonic) &&
+        ok = dok && mag_ok(hl) && mag_nz(vl) && mag_nz(tv) && mag_nz(z) && rr > 1e-60 && rr < 1e60 && mag_nz(c_harmonic) &&
              mag_ok(cos_t);
     } else {
-        const T c_harmonic = z / (t.PS[il - 1] + hl / vl);
-        const T cos_t = z / sqrt(rr);
-        p0 = cos_t / c_harmonic;
+        const T c_harmonic = div_ieee(z, t.PS[il - 1] + div_ieee(hl, vl));
+        const T cos_t = div_ieee(z, T(sqrt(rr)));
+        p0 = div_ieee(cos_t, c_harmonic);
         ok = true;
     }
     const T vmax = t.VMAX[il];
@@ -753,11 +833,12 @@ __device__ __forceinline__ T straight_time(T z, T R, T v0)
 {
     const T rr = z * z + R * R;
     if constexpr (std::is_same<T, double>::value) {
-        const bool ok = rr > 1e-60 && rr < 1e60 && mag_nz(v0);
+        bool ok = rr > 1e-60 && rr < 1e60 && mag_nz(v0);
+        const T tt = div_guarded(sqrt_guarded(rr), v0, ok);
         if (__all(ok))
-            return div_guarded(sqrt_guarded(rr), v0);
+            return tt;
     }
-    return sqrt(rr) / v0;
+    return div_ieee(T(sqrt(rr)), v0);
 }
 
 template <typename T>
@@ -792,7 +873,7 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     const bool isB0 = MODE == ADV_ANY && (st == ST_BIS0), isB = MODE != ADV_INIT_ONLY && (st == ST_BIS),
                isN = MODE != ADV_INIT_ONLY && (st == ST_NEWTON), isF = MODE != ADV_INIT_ONLY && (st == ST_FINAL);
     // cf/cfp of GetPTime (:138), deltax of solvebst (:384) and of solve (:294): same operands, one divide
-    const T q = f / fp;
+    const T q = solver_quotient(f, fp, st != ST_DONE);
     const bool neg = f < T(0.0);
     const bool small = fabs(f) < T(0.1);   // abs(fx) < tol (:287), abs(fmid) < tol (:394)
     const T safe = s.safe;  // 1/maxval(V)-(1d-10)      (:142, :388)
@@ -866,9 +947,9 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 // lane_advance for a lane in ST_INIT (the fused kernel's first-evaluation pass): GetPTime's branch (:136-153) after
 // cf = f(p0), cfp = f'(p0).  Same operations on the same operands as lane_advance.
 template <typename T>
-__device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp)
+__device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp, bool live)
 {
-    const T q = f / fp;                        // cf/cfp (:138)
+    const T q = solver_quotient(f, fp, live);  // cf/cfp (:138)
     const bool neg = f < T(0.0);
     const bool small = fabs(f) < T(0.1);       // abs(fx) < tol (:287) of solve's first trip
     const T check_x = s.xe - q;                // check_x = p0 - cf/cfp (:138)
@@ -893,7 +974,7 @@ template <typename T>
 __device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
-    const T q = f / fp;                      // deltax of solvebst (:384) and of solve (:294)
+    const T q = solver_quotient(f, fp, st != ST_DONE);  // deltax of solvebst (:384) and of solve (:294)
     const bool neg = f < T(0.0);
     const bool small = fabs(f) < T(0.1);     // abs(fx) < tol (:287), abs(fmid) < tol (:394)
     if (st == ST_BIS) {
@@ -953,9 +1034,9 @@ __device__ __forceinline__ bool travel_time_terms(const LayerTable<T> &t, T p, i
 #pragma unroll 1
         for (int i = 0; i < nfull_wave; ++i) {
             const int j = i < nfull ? i : t.nul;
-            tt = tt + t.H[j] / (t.V[j] * sqrt(T(1.0) - pp * t.VV[j]));
+            tt = tt + div_ieee(t.H[j], T(t.V[j] * sqrt(T(1.0) - pp * t.VV[j])));
         }
-        tt = tt + hl / (t.V[il] * sqrt(T(1.0) - pp * t.VV[il]));
+        tt = tt + div_ieee(hl, T(t.V[il] * sqrt(T(1.0) - pp * t.VV[il])));
         tt_out = tt;
         return true;
     }
@@ -988,13 +1069,18 @@ __device__ __forceinline__ bool travel_time_terms(const LayerTable<T> &t, T p, i
             c1 = __builtin_fma(-n1, r1, 1.0);
             r0 = __builtin_fma(r0, c0, r0);
             r1 = __builtin_fma(r1, c1, r1);
+            c0 = __builtin_fma(-n0, r0, 1.0);  // third step: correctly rounded reciprocals (see div_guarded)
+            c1 = __builtin_fma(-n1, r1, 1.0);
+            r0 = __builtin_fma(r0, c0, r0);
+            r1 = __builtin_fma(r1, c1, r1);
             const double q0 = h0 * r0, q1 = h1 * r1;
             t0 = __builtin_fma(__builtin_fma(-n0, q0, h0), r0, q0);
             t1 = __builtin_fma(__builtin_fma(-n1, q1, h1), r1, q1);
-            ok = ok && w0 > 1e-60 && w1 > 1e-60;
+            ok = ok && w0 > 1e-60 && w1 > 1e-60 &&
+                 max((uint32_t)__double2loint(n0), (uint32_t)__double2loint(n1)) != 0xFFFFFFFFu;
         } else {
-            t0 = h0 / (v0 * sqrt(w0));
-            t1 = h1 / (v1 * sqrt(w1));
+            t0 = div_ieee(h0, T(v0 * sqrt(w0)));
+            t1 = div_ieee(h1, T(v1 * sqrt(w1)));
         }
         tt = tt + t0;
         tt = tt + t1;

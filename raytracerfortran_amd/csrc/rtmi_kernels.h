@@ -83,7 +83,12 @@ hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_n
 hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
                                           unsigned long long *d_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,
-                                      unsigned long long *d_out, hipStream_t stream);
+                                      unsigned long long *d_out, int extended, hipStream_t stream);
+hipError_t rtmi_launch_fastmath_values(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                                       double *o_div, double *o_divg, double *o_sqrt, double *o_tf, double *o_tp,
+                                       hipStream_t stream);
+hipError_t rtmi_launch_fastmath_values_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
+                                           float *o_div, float *o_tf, float *o_tp, hipStream_t stream);
 int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus);
 hipError_t rtmi_launch_trace(const rtmi::TraceArgs *args, int nmodels, int max_nlayers, int grid_x,
                              hipStream_t stream);

@@ -88,7 +88,7 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
         tt = -T(999.0);
     p_out = s.x;
     if (straight) {
-        tt = sqrt(z * z + R * R) / t.V[0];
+        tt = div_ieee(T(sqrt(z * z + R * R)), t.V[0]);
         p_out = __builtin_nan("");
     }
     return tt;
@@ -423,8 +423,13 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const int nfw = wave_max_i32(live ? s.nfull : 0);
             T f, fp;
             eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
-            if (live)
-                lane_advance_init(s, f, fp);
+            {
+                // every lane of the wave takes part (wave-uniform choice of the divide); dead lanes are restored
+                const Lane<T> keep = s;
+                lane_advance_init(s, f, fp, live);
+                if (!live)
+                    s = keep;
+            }
             if (valid) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
@@ -840,26 +845,38 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
 // Diagnostic: bitwise comparison of the guarded sqrt/divide with the plain operators.
 // out[0] += sqrt mismatches over w[], out[1] += divide mismatches over (num[], den[]),
 // out[2] += mismatches of the shared-reciprocal layer term (w[], numerators num[] and den[]).
+// EX: also out[3] += term mismatches counted WITHOUT regard to the term's own guard (what the kernels would return if the
+// all-ones-divisor guard were compiled out) and out[4] += operands that guard rejected.
+template <bool EX>
 __global__ void fastmath_check_kernel(const double *__restrict__ w, const double *__restrict__ num,
                                       const double *__restrict__ den, int64_t n, unsigned long long *out)
 {
-    unsigned long long bad_s = 0, bad_d = 0, bad_t = 0;
+    unsigned long long bad_s = 0, bad_d = 0, bad_t = 0, bad_raw = 0, rejected = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double a = sqrt_guarded(w[i]);
         const double b = sqrt(w[i]);
         bad_s += (__double_as_longlong(a) != __double_as_longlong(b));
-        const double c = div_guarded(num[i], den[i]);
-        const double d = num[i] / den[i];
-        bad_d += (__double_as_longlong(c) != __double_as_longlong(d));
+        bool dok = true;
+        const double c = div_guarded(num[i], den[i], dok);
+        const double d = div_ieee(num[i], den[i]);
+        bad_d += dok && (__double_as_longlong(c) != __double_as_longlong(d));
         // the shared-reciprocal layer term against sqrt and two plain divides (num[i] plays H*V*x, den[i] H*V)
         const double wa[1] = {w[i]}, na[1] = {num[i]}, da[1] = {den[i]};
         double tf[1], tp[1];
         const bool sound = term_guarded_n<1>(wa, na, da, tf, tp);  // false: the kernels would take the plain operators
-        const double tf_ref = num[i] / b;
-        const double tp_ref = den[i] / ((b * b) * b);
+        const double tf_ref = div_ieee(num[i], b);
+        const double tp_ref = div_ieee(den[i], (b * b) * b);
+        const unsigned long long mis = (__double_as_longlong(tf[0]) != __double_as_longlong(tf_ref)) +
+                                       (__double_as_longlong(tp[0]) != __double_as_longlong(tp_ref));
         if (sound)
-            bad_t += (__double_as_longlong(tf[0]) != __double_as_longlong(tf_ref)) +
-                     (__double_as_longlong(tp[0]) != __double_as_longlong(tp_ref));
+            bad_t += mis;
+        if (EX && mis) {  // the first 58 offending operand indices (bit 63: the guard had accepted it), for the report
+            const unsigned long long slot = atomicAdd(&out[5], 1ull);
+            if (slot < 58)
+                out[6 + slot] = (unsigned long long)i | (sound ? 1ull << 63 : 0ull);
+        }
+        bad_raw += mis;
+        rejected += !sound;
     }
     if (bad_s)
         atomicAdd(&out[0], bad_s);
@@ -867,6 +884,12 @@ __global__ void fastmath_check_kernel(const double *__restrict__ w, const double
         atomicAdd(&out[1], bad_d);
     if (bad_t)
         atomicAdd(&out[2], bad_t);
+    if (EX) {
+        if (bad_raw)
+            atomicAdd(&out[3], bad_raw);
+        if (rejected)
+            atomicAdd(&out[4], rejected);
+    }
 }
 
 // single precision: the layer term against sqrtf and two plain divides; out[0] += mismatches of num/sqrt(w),
@@ -880,8 +903,8 @@ __global__ void fastmath_check_kernel_f32(const float *__restrict__ w, const flo
         float tf[1], tp[1];
         const bool sound = term_guarded_n<1>(wa, na, da, tf, tp);
         const float s = sqrtf(w[i]);
-        const float tf_ref = num[i] / s;
-        const float tp_ref = den[i] / ((s * s) * s);
+        const float tf_ref = div_ieee(num[i], s);
+        const float tp_ref = div_ieee(den[i], (s * s) * s);
         if (sound) {
             bad_f += (__float_as_uint(tf[0]) != __float_as_uint(tf_ref));
             bad_p += (__float_as_uint(tp[0]) != __float_as_uint(tp_ref));
@@ -893,7 +916,55 @@ __global__ void fastmath_check_kernel_f32(const float *__restrict__ w, const flo
         atomicAdd(&out[1], bad_p);
 }
 
+// Diagnostic: the VALUES the kernels' arithmetic building blocks return, for comparison with an IEEE host (numpy):
+//   o_div = div_ieee(num, den), o_divg = div_guarded(num, den) (NaN where its guard rejects), o_sqrt = sqrt_guarded(w),
+//   o_tf / o_tp = the shared-reciprocal layer term num / sqrt(w), den / sqrt(w)^3 (NaN where the term's guard rejects).
+template <typename T>
+__global__ void fastmath_values_kernel(const T *__restrict__ w, const T *__restrict__ num, const T *__restrict__ den,
+                                       int64_t n, T *o_div, T *o_divg, T *o_sqrt, T *o_tf, T *o_tp)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (o_div)
+            o_div[i] = div_ieee(num[i], den[i]);
+        if constexpr (std::is_same<T, double>::value) {
+            if (o_divg) {
+                bool ok = true;
+                const double v = div_guarded(num[i], den[i], ok);
+                o_divg[i] = ok ? v : __builtin_nan("");
+            }
+            if (o_sqrt)
+                o_sqrt[i] = sqrt_guarded(w[i]);
+        }
+        if (o_tf || o_tp) {
+            const T wa[1] = {w[i]}, na[1] = {num[i]}, da[1] = {den[i]};
+            T tf[1], tp[1];
+            const bool sound = term_guarded_n<1>(wa, na, da, tf, tp);
+            if (o_tf)
+                o_tf[i] = sound ? tf[0] : T(__builtin_nan(""));
+            if (o_tp)
+                o_tp[i] = sound ? tp[0] : T(__builtin_nan(""));
+        }
+    }
+}
+
 }  // namespace rtmi
+
+extern "C" hipError_t rtmi_launch_fastmath_values(const double *d_w, const double *d_num, const double *d_den, int64_t n,
+                                                  double *o_div, double *o_divg, double *o_sqrt, double *o_tf,
+                                                  double *o_tp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rtmi::fastmath_values_kernel<double>, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, o_div,
+                       o_divg, o_sqrt, o_tf, o_tp);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtmi_launch_fastmath_values_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
+                                                      float *o_div, float *o_tf, float *o_tp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rtmi::fastmath_values_kernel<float>, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, o_div,
+                       (float *)nullptr, (float *)nullptr, o_tf, o_tp);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Launchers (host).  No allocation, no synchronisation: graph-capturable.
@@ -1114,8 +1185,11 @@ extern "C" hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const flo
 }
 
 extern "C" hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den,
-                                                 int64_t n, unsigned long long *d_out, hipStream_t stream)
+                                                 int64_t n, unsigned long long *d_out, int extended, hipStream_t stream)
 {
-    hipLaunchKernelGGL(rtmi::fastmath_check_kernel, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, d_out);
+    if (extended)
+        hipLaunchKernelGGL(rtmi::fastmath_check_kernel<true>, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, d_out);
+    else
+        hipLaunchKernelGGL(rtmi::fastmath_check_kernel<false>, dim3(2048), dim3(256), 0, stream, d_w, d_num, d_den, n, d_out);
     return hipGetLastError();
 }

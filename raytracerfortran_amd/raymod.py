@@ -82,6 +82,9 @@ SIGNATURES = {
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
     "rtmi_debug_stamps": (ctypes.c_int, [_vp]),
     "rtmi_selftest_fastmath": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    "rtmi_selftest_fastmath_ex": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    "rtmi_selftest_values": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtmi_selftest_values_f32": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "rtmi_selftest_fastmath_f32": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     "rtmi_write_rays_dat": (ctypes.c_int, [ctypes.c_char_p, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int64]),
 }
@@ -503,6 +506,47 @@ def selftest_fastmath_f32(w, num, den):
                                           _ptr(out, torch.int64, "out"), _stream_ptr(None)))
     torch.cuda.synchronize()
     return int(out[0]), int(out[1])
+
+
+def selftest_values(w, num, den):
+    """Values of the kernels' divide / guarded divide / guarded sqrt / layer term on the given CUDA tensors (float64:
+    rtmi_selftest_values -> dict div, div_guarded, sqrt, tf, tp; float32: rtmi_selftest_values_f32 -> div, tf, tp).
+    NaN marks operands a guard rejects (the kernels then take the plain operators)."""
+    import torch
+    lib = load_library()
+    n = int(w.numel())
+    if num.numel() != n or den.numel() != n:
+        raise ValueError("size mismatch")
+    dt = w.dtype
+    names = ("div", "div_guarded", "sqrt", "tf", "tp") if dt == torch.float64 else ("div", "tf", "tp")
+    out = {k: torch.empty(n, dtype=dt, device=w.device) for k in names}
+    if dt == torch.float64:
+        _check(lib.rtmi_selftest_values(_ptr(w, dt, "w"), _ptr(num, dt, "num"), _ptr(den, dt, "den"), n,
+                                        *[_ptr(out[k], dt, k) for k in names], _stream_ptr(None)))
+    else:
+        _check(lib.rtmi_selftest_values_f32(_ptr(w, dt, "w"), _ptr(num, dt, "num"), _ptr(den, dt, "den"), n,
+                                            *[_ptr(out[k], dt, k) for k in names], _stream_ptr(None)))
+    torch.cuda.synchronize()
+    return out
+
+
+def selftest_fastmath_ex(w, num, den):
+    """selftest_fastmath plus (term mismatches with the all-ones guard ignored, operands that guard rejected)
+    (rtmi_selftest_fastmath_ex): 5 counts."""
+    import torch
+    lib = load_library()
+    n = int(w.numel())
+    if num.numel() != n or den.numel() != n:
+        raise ValueError("size mismatch")
+    out = torch.zeros(64, dtype=torch.int64, device=w.device)
+    f64 = torch.float64
+    _check(lib.rtmi_selftest_fastmath_ex(_ptr(w, f64, "w"), _ptr(num, f64, "num"), _ptr(den, f64, "den"), n,
+                                         _ptr(out, torch.int64, "out"), _stream_ptr(None)))
+    torch.cuda.synchronize()
+    o = [int(x) for x in out]
+    # (index, accepted by the guard) of the first operands whose fast-form term differs from the plain operators
+    selftest_fastmath_ex.last_offenders = [(x & ((1 << 62) - 1), x < 0) for x in o[6:6 + min(o[5], 58)]]
+    return tuple(o[:5])
 
 
 def selftest_fastmath(w, num, den):
