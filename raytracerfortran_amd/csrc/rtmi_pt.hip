@@ -73,34 +73,51 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
 #define PT_BLOCK 64
 
 // One thread per chain: [decide the previous slot] [sigma move] [propose the next slot].
+// LDS per block: the chains' current and proposed nodes (staged cooperatively, coalesced, in ONE round trip to HBM
+// together with the threads' scalar state), the depth-order scratch and the Poisson table.
 __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
 {
     extern __shared__ __attribute__((aligned(16))) double pt_lds[];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.nchains)
-        return;
-    double *qz = pt_lds + (size_t)threadIdx.x * d.K;
-    double *qv = pt_lds + (size_t)PT_BLOCK * d.K + (size_t)threadIdx.x * d.K;
-    int *ord = reinterpret_cast<int *>(pt_lds + (size_t)2 * PT_BLOCK * d.K) + (size_t)threadIdx.x * d.K;
+    const int K = d.K;
+    double *l_cz = pt_lds, *l_cv = l_cz + PT_BLOCK * K, *l_pz = l_cv + PT_BLOCK * K, *l_pv = l_pz + PT_BLOCK * K;
+    double *l_lpk = l_pv + PT_BLOCK * K;                                   // [K + 2]
+    int *l_ord = reinterpret_cast<int *>(l_lpk + K + 2);                    // [PT_BLOCK][K]
+    const int c0 = blockIdx.x * PT_BLOCK;
+    const int nloc = d.nchains - c0 < PT_BLOCK ? d.nchains - c0 : PT_BLOCK;
+    for (int i = threadIdx.x; i < nloc * K; i += PT_BLOCK) {
+        l_cz[i] = d.z[(size_t)c0 * K + i];
+        l_cv[i] = d.v[(size_t)c0 * K + i];
+        l_pz[i] = d.pz[(size_t)c0 * K + i];
+        l_pv[i] = d.pv[(size_t)c0 * K + i];
+    }
+    for (int i = threadIdx.x; i < K + 2; i += PT_BLOCK)
+        l_lpk[i] = d.logpk[i];
+    const int c = c0 + threadIdx.x;
+    const bool mine = c < d.nchains;
+    const int cc = mine ? c : c0;  // threads without a chain shadow the block's first one and write nothing
     const rtmi_pt_prior &p = d.pr;
-    // everything the thread will need, requested up front (independent loads: one round trip, not a chain of them)
-    int k = d.k[c];
-    const int act = d.pactive[c];
-    const int pk = d.pk[c];
-    const unsigned long long ctr0 = d.ctr[c];
-    double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
-    const double beta = d.beta[c], plp = d.plp[c];
-    double *zc = d.z + (size_t)c * d.K, *vc = d.v + (size_t)c * d.K;
-    double *pz = d.pz + (size_t)c * d.K, *pv = d.pv + (size_t)c * d.K;
-    long long *st = d.stats + (size_t)c * 8;
+    int k = d.k[cc];
+    const int act = d.pactive[cc];
+    const int pk = d.pk[cc];
+    const unsigned long long ctr0 = d.ctr[cc];
+    double sd = d.sd[cc], logL = d.logL[cc], ss = d.ss[cc];
+    const double beta = d.beta[cc], plp = d.plp[cc];
     double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
     if (decide != PT_NONE && act != 0)
         for (int i = 0; i < d.gx; ++i)
-            part = part + d.partial[(size_t)c * d.gx + i];
+            part = part + d.partial[(size_t)cc * d.gx + i];
+    __syncthreads();
+    if (!mine)
+        return;
+    double *qz = l_cz + (size_t)threadIdx.x * K, *qv = l_cv + (size_t)threadIdx.x * K;
+    const double *lz = l_pz + (size_t)threadIdx.x * K, *lv = l_pv + (size_t)threadIdx.x * K;
+    int *ord = l_ord + (size_t)threadIdx.x * K;
+    double *zc = d.z + (size_t)c * K, *vc = d.v + (size_t)c * K;
+    double *pz = d.pz + (size_t)c * K, *pv = d.pv + (size_t)c * K;
+    long long *st = d.stats + (size_t)c * 8;
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
 
     // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
-    bool accepted = false;
     if (decide != PT_NONE && act != 0) {
         const double logl_new = R::gaussian_loglike(part, d.ndata, sd);
         if (act == 2) {
@@ -112,22 +129,20 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
                 lr = 50.0;
             st[2 * decide + 1] += 1;
             if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
-                accepted = true;
                 k = pk;
                 ss = part;
                 logL = logl_new;
                 st[2 * decide] += 1;
+                d.k[c] = k;
+                for (int i = 0; i < k; ++i) {  // the proposal becomes the state: LDS copy and HBM
+                    qz[i] = lz[i];
+                    qv[i] = lv[i];
+                    zc[i] = lz[i];
+                    vc[i] = lv[i];
+                }
             }
         }
         d.pactive[c] = 0;
-    }
-    // the chain's (possibly just accepted) nodes into the thread's LDS arrays
-    load_nodes(accepted ? pz : zc, qz, k);
-    load_nodes(accepted ? pv : vc, qv, k);
-    if (accepted) {
-        d.k[c] = k;
-        load_nodes(qz, zc, k);
-        load_nodes(qv, vc, k);
     }
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
                     qz[k] = (p.hmx - p.hmin) * R::philox_uniform(rng);
                     qv[k] = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
                     qk = k + 1;
-                    lp = d.logpk[k + 1] - d.logpk[k];
+                    lp = l_lpk[k + 1] - l_lpk[k];
                     have = true;
                 } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
                     int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
                         qv[i] = qv[i + 1];
                     }
                     qk = k - 1;
-                    lp = d.logpk[k - 1] - d.logpk[k];
+                    lp = l_lpk[k - 1] - l_lpk[k];
                     have = true;
                 }
             }
@@ -254,11 +269,23 @@ __global__ void pt_swap_kernel(int nct, int first, int nloc, const double *logl_
     for (int i = threadIdx.x; i < nlevels; i += blockDim.x)
         s_beta[i] = beta_of_level[i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        long long prop = 0;
-        const int acc = R::swap_decide(nct, s_logl, s_level, s_beta, seed, round, s_order, &prop);
-        swstats[0] += acc;
-        swstats[1] += prop;
+    // one thread per chain: its position in the (level, index) order; then one thread per pair (the pairs are disjoint)
+    for (int i = threadIdx.x; i < nct; i += blockDim.x)
+        s_order[R::swap_position(nct, s_level, i)] = i;
+    __syncthreads();
+    const int par = (int)(round & 1ull);
+    for (int j = threadIdx.x; par + 2 * j + 1 < nct; j += blockDim.x) {
+        const int a = par + 2 * j;
+        const bool acc = R::swap_pair(a, s_order, s_logl, s_level, s_beta, seed, round);
+        if (acc) {
+            const int c1 = s_order[a], c2 = s_order[a + 1];
+            const int t = s_level[c1];
+            s_level[c1] = s_level[c2];
+            s_level[c2] = t;
+        }
+        atomicAdd((unsigned long long *)&swstats[1], 1ull);
+        if (acc)
+            atomicAdd((unsigned long long *)&swstats[0], 1ull);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nct; i += blockDim.x)
@@ -330,7 +357,10 @@ struct rtmi_pt {
 namespace {
 
 int blocks_for(int n) { return (n + PT_BLOCK - 1) / PT_BLOCK; }
-size_t step_lds(const rtmi_pt *h) { return (size_t)PT_BLOCK * (size_t)h->K * (2 * sizeof(double) + sizeof(int)); }
+size_t step_lds(const rtmi_pt *h)
+{
+    return (size_t)PT_BLOCK * (size_t)h->K * (4 * sizeof(double) + sizeof(int)) + ((size_t)h->K + 2) * sizeof(double);
+}
 
 int launch_likelihood(rtmi_pt *h)
 {
@@ -464,7 +494,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         return nullptr;
     {
         // the sweep kernels keep K doubles x 2 + K ints per thread in LDS: above 64 KiB that needs the opt-in
-        const size_t need = (size_t)PT_BLOCK * (size_t)prior->kmax * (2 * sizeof(double) + sizeof(int));
+        const size_t need = (size_t)PT_BLOCK * (size_t)prior->kmax * (4 * sizeof(double) + sizeof(int)) +
+                            ((size_t)prior->kmax + 2) * sizeof(double);
         if (need > 64 * 1024 &&
             (hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)need) != hipSuccess ||

@@ -153,35 +153,44 @@ RTMI_HD int pack_model(const double *z, const double *v, int k, const int *ord, 
 // stream (seed, 0xFFFFFFFF, r, a), so every rank takes identical decisions without talking.  `order` is scratch of
 // nchains ints.  Returns accepted swaps; *proposed += pairs tried.  The reference's pairing -- the first two workers
 // that report to rank 0 (:331-349) -- depends on MPI timing and is deliberately not reproduced.
+// The two steps of a swap round, usable one chain / one pair at a time (the device runs them with one thread each):
+// position of chain i when the chains are ordered by (level, chain index) ...
+RTMI_HD int swap_position(int nchains, const int *level, int i)
+{
+    int pos = 0;
+    const int li = level[i];
+    for (int j = 0; j < nchains; ++j)
+        pos += (level[j] < li) || (level[j] == li && j < i);
+    return pos;
+}
+
+// ... and the decision for the pair at positions (a, a + 1) of that order: true = the two chains swap their levels.
+RTMI_HD bool swap_pair(int a, const int *order, const double *logl, const int *level, const double *beta_of_level,
+                       uint64_t seed, uint64_t round)
+{
+    const int c1 = order[a], c2 = order[a + 1];
+    const double b1 = beta_of_level[level[c1]], b2 = beta_of_level[level[c2]];
+    Philox p = philox_make(seed, 0xFFFFFFFFu, (uint32_t)round, ((uint64_t)(round >> 32) << 32) | (uint32_t)a);
+    const double u = philox_uniform(p);
+    if (b1 == b2)
+        return false;
+    double lr = (b2 - b1) * (logl[c1] - logl[c2]);
+    if (lr > 50.0)
+        lr = 50.0;
+    return u <= exp(lr);
+}
+
 RTMI_HD int swap_decide(int nchains, const double *logl, int *level, const double *beta_of_level, uint64_t seed,
                         uint64_t round, int *order, long long *proposed)
 {
-    // chains by level, ties by chain index (stable): counting by insertion, nchains is a few hundred at most
     for (int i = 0; i < nchains; ++i)
-        order[i] = i;
-    for (int i = 1; i < nchains; ++i) {
-        const int o = order[i];
-        int j = i - 1;
-        while (j >= 0 && level[order[j]] > level[o]) {
-            order[j + 1] = order[j];
-            --j;
-        }
-        order[j + 1] = o;
-    }
+        order[swap_position(nchains, level, i)] = i;
     int acc = 0;
-    for (int a = (int)(round & 1ull); a + 1 < nchains; a += 2) {
-        const int c1 = order[a], c2 = order[a + 1];
-        const double b1 = beta_of_level[level[c1]], b2 = beta_of_level[level[c2]];
-        Philox p = philox_make(seed, 0xFFFFFFFFu, (uint32_t)round, ((uint64_t)(round >> 32) << 32) | (uint32_t)a);
-        const double u = philox_uniform(p);
+    for (int a = (int)(round & 1ull); a + 1 < nchains; a += 2) {  // the pairs are disjoint: any order of evaluation
         if (proposed)
             *proposed += 1;
-        if (b1 == b2)
-            continue;
-        double lr = (b2 - b1) * (logl[c1] - logl[c2]);
-        if (lr > 50.0)
-            lr = 50.0;
-        if (u <= exp(lr)) {
+        if (swap_pair(a, order, logl, level, beta_of_level, seed, round)) {
+            const int c1 = order[a], c2 = order[a + 1];
             const int t = level[c1];
             level[c1] = level[c2];
             level[c2] = t;
