@@ -86,6 +86,17 @@ DEF_KERNEL(k_cmp_f64, asm volatile("v_cmp_gt_f64 vcc, %0, %1\nv_cmp_gt_f64 vcc, 
                                    "v_cmp_gt_f64 vcc, %4, %5\nv_cmp_gt_f64 vcc, %5, %6\nv_cmp_gt_f64 vcc, %6, %7\nv_cmp_gt_f64 vcc, %7, %0"
                                    ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "vcc");)
 
+#define OP3_F32(op)                                                                                          \
+    asm volatile(op " %0, %0, %8, %9\n" op " %1, %1, %8, %9\n" op " %2, %2, %8, %9\n" op " %3, %3, %8, %9\n" op \
+                    " %4, %4, %8, %9\n" op " %5, %5, %8, %9\n" op " %6, %6, %8, %9\n" op " %7, %7, %8, %9"       \
+                 : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)               \
+                 : "v"((float)b), "v"((float)c));
+// single precision, scalar and packed (two floats per lane in a 64-bit register pair: the double registers serve as containers)
+DEF_KERNEL(k_fma_f32, OP3_F32("v_fma_f32"))
+DEF_KERNEL(k_pk_fma_f32, OP3_F64("v_pk_fma_f32"))
+DEF_KERNEL(k_pk_mul_f32, OP2_F64("v_pk_mul_f32"))
+DEF_KERNEL(k_pk_add_f32, OP2_F64("v_pk_add_f32"))
+
 typedef void (*kern_t)(double *, unsigned long long *, double);
 
 int main()
@@ -95,7 +106,8 @@ int main()
         {"v_rsq_f64", k_rsq_f64}, {"v_sqrt_f64", k_sqrt_f64}, {"v_rcp_f32", k_rcp_f32}, {"v_rsq_f32", k_rsq_f32},
         {"v_div_scale_f64", k_divscale_f64}, {"v_div_fmas_f64", k_fmas_f64}, {"v_div_fixup_f64", k_fixup_f64},
         {"v_ldexp_f64", k_ldexp_f64}, {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32},
-        {"v_cndmask_b32", k_cndmask}, {"v_cmp_gt_f64", k_cmp_f64}};
+        {"v_cndmask_b32", k_cndmask}, {"v_cmp_gt_f64", k_cmp_f64}, {"v_fma_f32", k_fma_f32},
+        {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}};
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
