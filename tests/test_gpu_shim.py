@@ -23,10 +23,16 @@ def test_fortran_tracerays_caller(kat):
     p = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     lines_out = p.stdout.strip().splitlines()
-    t = np.array([float(x) for ln in lines_out if not ln.startswith("LOGL") for x in ln.split()])
+    t = np.array([float(x) for ln in lines_out if not ln.startswith(("LOGL", "PT")) for x in ln.split()])
     assert compare_times(t, kat["config1_ref_timeP"], 1e-9) == 0.0
     # module rtmi_likelihood: rtmi_set_sources + rtmi_loglhood_batch from Fortran (obs = predictions -> SS = 0)
     tag, rc, logl, ss = [ln for ln in lines_out if ln.startswith("LOGL")][0].split()
     n = len(off)
     assert int(rc) == 0 and float(ss) == 0.0
     assert abs(float(logl) - (-0.5 * n * np.log(2 * np.pi) - n * np.log(0.02))) < 1e-10
+    # module rtmi_sampler: the GPU-resident sweep + exchange through a one-rank RCCL communicator, driven from Fortran
+    f = [ln for ln in lines_out if ln.startswith("PT")][0].split()
+    assert int(f[1]) == 0, f
+    assert abs(float(f[2]) - float(logl)) < 1e-9            # rtmi_pt_evaluate of the model = the batch likelihood above
+    assert all(1 <= int(x) <= 10 for x in f[3:7])
+    assert sorted(float(x) for x in f[7:11]) == [0.35, 0.5, 0.7, 1.0]   # the ladder is a permutation of itself
