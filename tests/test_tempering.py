@@ -420,3 +420,44 @@ def test_two_handles_own_their_source_sets(kat):
     rt.set_sources(off1, dep1, obs1)
     with pytest.raises(RuntimeError, match="replaced"):
         ev([nodes])
+
+
+@pytest.mark.gpu
+def test_device_sweep_config4_miniature_k_up_to_30():
+    """BASELINE config 4's model space (k in [2, 30], 60 proposal slots per sweep, > 64 KiB of LDS in the step kernel)
+    in miniature: 16 chains over 3000 sources start from a 12-layer model, sweeps with exchanges; every chain stays
+    inside the prior's bounds and its logL equals an independent evaluation of its final state by the oracle."""
+    from oracle import oracle as O
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod, synthetic as S
+    off, dep = S.sampler_sources(3000, 77)
+    rng = np.random.default_rng(78)
+    z = np.concatenate([[0.0], np.sort(rng.uniform(300.0, 9000.0, 11))])
+    z[1:] += np.arange(11) * 150.0                      # keep the layers thicker than hmin
+    v = rng.uniform(2000.0, 8000.0, 12)
+    nodes = np.column_stack([z, v])
+    vv, dd = T.layering(nodes)
+    obs = O.oracle_dff(vv, dd, off, dep) + rng.normal(0.0, 0.02, off.size)
+    rt.set_sources(off, dep, obs)
+    pr = T.Prior(kmin=2, kmax=30, lam=10.0)
+    n = 16
+    nat = raymod.NativeChains(n, 31, off.size, pr, seed=9, stream_id=0)
+    for i in range(n):
+        nat.set_chain(i, nodes, 0.02, 1.0)
+    nat.evaluate()
+    ref0 = O.oracle_loglhood_rt(obs, O.oracle_dff(vv, dd, off, dep), 0.02, stable=True)
+    assert np.all(np.abs(nat.logl() - ref0) <= 1e-10 * abs(ref0))
+    nat.set_ladder(n, 0, np.arange(n), 1.2 ** -np.arange(float(n)))
+    nat.run(40, 1, None, 0)
+    a = nat.get_all()
+    st = nat.stats()
+    assert st["acc_bd"] > 0 and st["acc_mh"] > 0 and a["k"].min() >= 2 and a["k"].max() <= 30 and len(set(a["k"])) > 1
+    for i in range(n):
+        k = int(a["k"][i])
+        c_nodes = np.column_stack([a["z"][i, :k], a["v"][i, :k]])
+        assert T.inside_bounds(c_nodes, pr)
+        v2, d2 = T.layering(c_nodes)
+        ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v2, d2, off, dep), a["sd"][i], stable=True)
+        assert abs(a["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref)), (i, k)
+    lev, acc, prop = nat.get_ladder()
+    assert sorted(lev.tolist()) == list(range(n)) and prop == 40 * 8 - 20   # 8 pairs on even rounds, 7 on odd ones
