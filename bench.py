@@ -200,13 +200,25 @@ def dropin_figures(rt, v, d, off, dep, ref_t=None):
     out["pcie_floor_ms"] = 24.0 * n / 63e9 * 1e3
     if ref_t is not None:
         out["dff_large_bit_equal_to_device_path"] = bool(np.array_equal(t_big, ref_t))
+    # fresh arrays on every call (R's .Fortran hands over newly allocated copies): the pages have to be pinned anew
+    fresh, keep = [], []
+    for _ in range(8):
+        o2, z2 = off.copy(), dep.copy()
+        f, t2 = caller(d.size, o2, z2)
+        keep.append((o2, z2, t2))
+        t0 = time.perf_counter()
+        f()
+        fresh.append(time.perf_counter() - t0)
+    out["dff_large_fresh_arrays_ms"] = float(np.median(fresh)) * 1e3
+    del keep
     small, _ = caller(d.size, np.ascontiguousarray(off[:20]), np.ascontiguousarray(dep[:20]))
     med20, best20 = median_ms(small, 300, 20)
     out["dff_nsrc20_us"] = med20 * 1e3
     out["dff_nsrc20_best_us"] = best20 * 1e3
     out["devices"] = os.environ.get("RTMI_DEVICES", "bound device only")
     out["note"] = ("host buffers in, host buffers out through the C symbol dff_ (pageable memory, PCIe inclusive); "
-                   "median of 15 calls at the bench size, of 300 calls at the reference's example size NSrc = 20")
+                   "median of 15 calls at the bench size on the same arrays (a Fortran caller's static buffers), of 8 calls on "
+                   "newly allocated arrays (R's .Fortran copies), of 300 calls at the reference's example size NSrc = 20")
     return out
 
 
