@@ -24,7 +24,7 @@ enum : int {
 
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of RTMI_TABLE_STRIDE(nlayers) elements; the pair
 // array HW comes first (16-byte aligned for the fp64 build) and takes two of them.
-#define RTMI_TABLE_ARRAYS 15
+#define RTMI_TABLE_ARRAYS 16
 #define RTMI_TRIP_CLASSES 3  // classes of trip_class (the fused kernel's solve order puts the Newton-only class after them)
 #ifndef RTMI_TERM_GROUP
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
@@ -64,6 +64,7 @@ struct LayerTable {
     T *PH;    // } is the source's own layer, thickness hl)                             1 <= il <= nlayers
     T *HVOK;  // HVOK[i] 1.0 if H and H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
               // (fast-path guards), else 0.0
+    T *PSA;   // PSA[i]  |HV[0]| + ... + |HV[i]|: bounds costFunc's sum at the bisection's first point (lane_setup)  i < nlayers
 };
 
 template <typename T>
@@ -86,6 +87,7 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool r
     t.PA = lds + 12 * n1;
     t.PC = lds + 13 * n1;
     t.PH = lds + 14 * n1;
+    t.PSA = lds + 15 * n1;
     t.HWR = rows ? reinterpret_cast<LayerPair<T> *>(lds + ((size_t)RTMI_TABLE_ARRAYS * n1 + 1) / 2 * 2) : nullptr;
     t.row_len = nlayers + 1;
     return t;
@@ -166,21 +168,22 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         // every lane loads its layer, then one scalar loop walks the lanes with readlane (no LDS round trip per
         // layer); the running values are the same in every lane, lane j keeps what they are after layer j.
         const int lane = threadIdx.x;
-        T s = T(0.0), m = T(0.0);
+        T s = T(0.0), m = T(0.0), sa = T(0.0);
         int jm = 0;           // first layer that carries the maximum (for the scheduling hint below)
         bool okrun = true;    // H, H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
         bool sorted = true;   // interfaces in non-decreasing order (no NaN): which_layer may search by bisection
         for (int base = 0; base <= nlayers; base += 64) {
             const int i = base + lane;
             const bool in = i <= nlayers, inl = i < nlayers;
-            const T v = in ? t.V[i] : T(0.0), q = inl ? t.Q[i] : T(0.0);
+            const T v = in ? t.V[i] : T(0.0), q = inl ? t.Q[i] : T(0.0), ahv = inl ? fabs(t.HV[i]) : T(0.0);
             const bool ok_l = !inl || (mag_ok(t.HV[i]) && mag_ok(t.H[i]) && mag_nz(v));
             const bool so_l = !(inl && i >= 1) || (t.D[i] >= t.D[i - 1]);
-            T vmax_l = T(0.0), ps_l = T(0.0);
+            T vmax_l = T(0.0), ps_l = T(0.0), psa_l = T(0.0);
             int jm_l = 0;
             const int cnt = nlayers + 1 - base < 64 ? nlayers + 1 - base : 64;
             for (int j = 0; j < cnt; ++j) {
                 const T vj = wave_readlane(v, j), qj = wave_readlane(q, j);
+                sa = sa + wave_readlane(ahv, j);
                 const int ij = base + j;
                 if (ij == 0) {
                     m = vj;
@@ -194,6 +197,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
                 if (lane == j) {
                     vmax_l = m;
                     ps_l = s;
+                    psa_l = sa;
                     jm_l = jm;
                 }
             }
@@ -208,6 +212,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             }
             if (inl) {
                 t.PS[i] = ps_l;
+                t.PSA[i] = psa_l;
                 t.HVOK[i] = hvok_l ? T(1.0) : T(0.0);
             }
         }
@@ -747,6 +752,7 @@ struct Lane {
     int k;        // trip counter of the current loop
     bool conv;
     bool numer_ok;  // hvl and the table products of the stack are inside eval_f_fp's fast-path guard
+    bool skip0;     // solvebst's first evaluation, f(x1 = 1d-10) (:354), is provably positive: only its sign is used
 };
 
 // The source's layer-dependent constants (InsertLayer :38-69 as table lookups).  il = nl - 1 >= 1.
@@ -763,6 +769,28 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
     s.clampv = s.vmi - T(1e-9);
     s.nfull = il;
     s.numer_ok = mag_ok(s.hvl) && (t.HVOK[il - 1] != T(0.0));
+    // solvebst starts with f1 = costFunc(x1 = 1d-10) and uses NOTHING of it but `f1 < 0` (:354-365).  The sum in f1 is
+    // at most x1 * SUM |H_i V_i| / min s_i, and with every velocity below 1e7 m/s  s_i = sqrt(1 - x1^2 V_i^2) > 0.9999995;
+    // the roundings of the products, quotients and of either sum are ~1e-13 relative.  So R > 1.01e-10 * SUM |H_i V_i|
+    // (a 1 % margin over all of that) proves f1 > 0 whatever the last bits are, and the evaluation -- one whole trip
+    // of the source, for two sources in three -- need not be made.  NaN or Inf anywhere makes the test false.
+    s.skip0 = s.R > T(1.01e-10) * (t.PSA[il - 1] + fabs(s.hvl)) && t.VMAX[il] < T(1e7);
+}
+
+// The state after solvebst's entry (:354-365) and its first `dx = dx*0.5; xmid = x + dx` (:368-369), given the sign of
+// f(x1): x1 = 1d-10, x2 = 1/maxval(vp) - 1d-12.
+template <typename T>
+__device__ __forceinline__ void lane_enter_bisection(Lane<T> &s, bool neg)
+{
+    const T e2 = s.vmi - T(1e-12);
+    const T e21 = e2 - T(1e-10);
+    const T b_x = neg ? T(1e-10) : e2;
+    const T b_dx = (neg ? e21 : -e21) * T(0.5);
+    s.xb = b_x;
+    s.dx = b_dx;
+    s.xe = b_x + b_dx;
+    s.k = 1;
+    s.st = ST_BIS;
 }
 
 // GetPTime head (:112-133): the starting ray parameter.  Returns NaN when the reference would loop
@@ -919,6 +947,10 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
                                       : bis_done ? ST_NEWTON
                                                  : n_go ? (kN == 15 ? ST_FINAL : ST_NEWTON)
                                                         : (n_conv || isF) ? ST_DONE : st;
+    if constexpr (MODE == ADV_ANY) {
+        if (initB && s.skip0)  // f(x1) is provably positive: straight to the first midpoint (see lane_setup)
+            lane_enter_bisection(s, false);
+    }
     if constexpr (MODE == ADV_NO_INIT) {
         const bool b0 = (st == ST_BIS0);  // untouched by everything above
         if (__any(b0)) {
@@ -1000,15 +1032,7 @@ __device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
         s.st = ST_DONE;
     } else if (st == ST_BIS0) {
         // solvebst entry (:354-365): x1 = 1d-10, x2 = 1/maxval(vp)-1d-12, then dx = dx*0.5; xmid = x + dx
-        const T e2 = s.vmi - T(1e-12);
-        const T e21 = e2 - T(1e-10);
-        const T b_x = neg ? T(1e-10) : e2;
-        const T b_dx = (neg ? e21 : -e21) * T(0.5);
-        s.xb = b_x;
-        s.dx = b_dx;
-        s.xe = b_x + b_dx;
-        s.k = 1;
-        s.st = ST_BIS;
+        lane_enter_bisection(s, neg);
     }
 }
 

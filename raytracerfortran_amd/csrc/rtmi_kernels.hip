@@ -533,6 +533,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         s.k = 0;
         s.conv = false;
         s.numer_ok = true;
+        s.skip0 = false;
         int slot = 0;
         int age = 0;             // trips this lane's source has taken in this wave
         bool exhausted = false;  // wave-uniform: the queue head has passed n_todo
@@ -714,6 +715,8 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                         if (key & RTMI_RK_SHORT) {
                             s.st = ST_NEWTON;  // solve(p0) after its first iteration
                             s.k = 2;
+                        } else if (s.skip0) {
+                            lane_enter_bisection(s, false);  // f(1e-10) > 0 without evaluating it (lane_setup)
                         } else {
                             s.st = ST_BIS0;    // solvebst(1d-10, ...): rp holds x1 = 1e-10
                         }
