@@ -24,7 +24,7 @@ enum : int {
 
 // The layer table of one model in LDS: RTMI_TABLE_ARRAYS arrays of RTMI_TABLE_STRIDE(nlayers) elements; the pair
 // array HW comes first (16-byte aligned for the fp64 build) and takes two of them.
-#define RTMI_TABLE_ARRAYS 16
+#define RTMI_TABLE_ARRAYS 16  // + 3 (SA, SC, HC) for models of up to RTMI_SKIP_MAX_NL interfaces: RTMI_TABLE_NARRAYS
 #define RTMI_TRIP_CLASSES 3  // classes of trip_class (the fused kernel's solve order puts the Newton-only class after them)
 #ifndef RTMI_TERM_GROUP
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
@@ -34,8 +34,11 @@ enum : int {
 // `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
 #define RTMI_ROWS_MAX_NL 20
 #define RTMI_HINT_MAX_NL 512  // deeper models: no ordering of the bisection sources by expected evaluations
-#define RTMI_TABLE_ELEMS(nlayers, rows) \
-    (((size_t)RTMI_TABLE_ARRAYS * RTMI_TABLE_STRIDE(nlayers) + 1) / 2 * 2 + \
+#define RTMI_SKIP_MAX_NL 64   // deeper models: no skipping of provably idle bisection trips (the bound's table is O(nlayers^2))
+// `skiptab` (like `rows`) is decided per LAUNCH from its largest model, so that the size is monotone in nlayers
+#define RTMI_TABLE_NARRAYS(skiptab) (RTMI_TABLE_ARRAYS + ((skiptab) ? 3 : 0))
+#define RTMI_TABLE_ELEMS(nlayers, rows, skiptab) \
+    (((size_t)RTMI_TABLE_NARRAYS(skiptab) * RTMI_TABLE_STRIDE(nlayers) + 1) / 2 * 2 + \
      ((rows) ? (size_t)2 * ((nlayers) + 1) * ((nlayers) + 1) : 0))
 template <typename T>
 struct alignas(2 * sizeof(T)) LayerPair {
@@ -65,10 +68,13 @@ struct LayerTable {
     T *HVOK;  // HVOK[i] 1.0 if H and H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
               // (fast-path guards), else 0.0
     T *PSA;   // PSA[i]  |HV[0]| + ... + |HV[i]|: bounds costFunc's sum at the bisection's first point (lane_setup)  i < nlayers
+    T *SA;    // } bound of costFunc's sum near the critical ray parameter (bisection_skip): for the stack whose
+    T *SC;    // } source layer is il, the full layers slower than its fastest contribute at most SA[il], the
+    T *HC;    // } partial layer hl * SC[il] (0 if it is the fastest), the fastest layers HC[il] * x / sqrt(1 - x^2 vmax^2)
 };
 
 template <typename T>
-__device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool rows = false)
+__device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool rows, bool skiptab)
 {
     const int n1 = RTMI_TABLE_STRIDE(nlayers);
     LayerTable<T> t;
@@ -88,7 +94,10 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool r
     t.PC = lds + 13 * n1;
     t.PH = lds + 14 * n1;
     t.PSA = lds + 15 * n1;
-    t.HWR = rows ? reinterpret_cast<LayerPair<T> *>(lds + ((size_t)RTMI_TABLE_ARRAYS * n1 + 1) / 2 * 2) : nullptr;
+    t.SA = skiptab ? lds + 16 * n1 : nullptr;
+    t.SC = skiptab ? lds + 17 * n1 : nullptr;
+    t.HC = skiptab ? lds + 18 * n1 : nullptr;
+    t.HWR = rows ? reinterpret_cast<LayerPair<T> *>(lds + ((size_t)RTMI_TABLE_NARRAYS(skiptab) * n1 + 1) / 2 * 2) : nullptr;
     t.row_len = nlayers + 1;
     return t;
 }
@@ -265,6 +274,46 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             t.PA[il] = (T)a;
             t.PC[il] = (T)c;
             t.PH[il] = j < il ? t.H[j] : T(0.0);
+        }
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        // The bound behind bisection_skip.  For the stack of a source in layer il (fastest velocity vmax, vmi = 1/vmax)
+        // and any x <= vmi, a layer slower than vmax contributes at most its term at x = vmi,
+        // H V vmi / sqrt(1 - vmi^2 V^2); the layers AT vmax contribute (sum of their H V) x / sqrt(1 - x^2 vmax^2).
+        // Approximate arithmetic (v_rsq_f64 + one Newton step, ~1e-9 relative) is enough: the bound is used with a
+        // 1e-6 margin and decides only which evaluations need not be made, never a value.  +Inf = "no bound" (negative
+        // thicknesses, unsorted interfaces, too many layers).
+        const bool usable = t.HVOK[nlayers] != T(0.0);
+        for (int il = 1 + (int)threadIdx.x; il <= nlayers && t.SA; il += blockDim.x) {
+            double sa = 0.0, hc = 0.0, sc = 0.0;
+            if (!usable) {
+                sa = INFINITY;
+            } else {
+                const double vmax = t.VMAX[il], vmi = div_ieee(1.0, vmax);
+                for (int i = 0; i <= il; ++i) {
+                    const double vi = t.V[i];
+                    const double hv = i < il ? t.HV[i] : 1.0;      // own layer: coefficient of its thickness hl times ...
+                    const double vfac = i < il ? 1.0 : vi;          // ... its velocity
+                    if (i < il && !(t.H[i] >= 0.0))
+                        sa = INFINITY;
+                    if (vi >= vmax) {
+                        if (i < il)
+                            hc += hv;
+                        continue;
+                    }
+                    const double y = vmi * vi, w = 1.0 - y * y;
+                    double r = __builtin_amdgcn_rsq(w);
+                    r = r * (1.5 - 0.5 * w * r * r);
+                    const double term = hv * vfac * vmi * r;
+                    if (i < il)
+                        sa += term;
+                    else
+                        sc = term;
+                }
+            }
+            t.SA[il] = sa;
+            t.SC[il] = sc;
+            t.HC[il] = hc;
         }
     }
     __syncthreads();
@@ -967,6 +1016,70 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
                 s.st = ST_BIS;
             }
         }
+    }
+}
+
+// Bisection trips that provably change nothing.  solvebst started with f(x1) > 0 walks xmid_k = x2 - (x2 - x1) 2^-k towards
+// the critical ray parameter; while f(xmid_k) >= tol (and f' < 0) a trip only halves dx: x stays x2, check = x2 - f/f' >
+// x2 > 1/vmax - 1d-10, no exit (:367-397).  f is decreasing in x when no thickness is negative, so ONE rigorous lower
+// bound f(xmid_m) > tol (costFunc's sum bounded from above through the table of stage_model, 1e-6 relative and 1e-4
+// absolute margins over the ~1e-10 noise of the computed sums) proves trips 1..m idle, and the source enters the
+// bisection at trip m + 1 with the state those trips would have left: dx = -(x2 - x1) 2^-(m+1) (halvings are exact),
+// xmid = x2 + dx, trip counter m + 1.  m is first estimated in closed form (two trips of slack), then VERIFIED at the
+// solver's own xmid_m; a failed verification just means no skip.  Returns m (0 = none).  Double precision only: in
+// single precision the noise of the sums is of the order of tol itself.
+template <typename T>
+__device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane<T> &s, int il, T hl)
+{
+    if constexpr (!std::is_same<T, double>::value) {
+        return 0;
+    } else {
+        if (!t.SA)
+            return 0;
+        const double vm = t.VMAX[il];
+        const bool own_crit = t.V[il] >= vm;
+        const double A = t.SA[il] + (own_crit ? 0.0 : hl * t.SC[il]);
+        const double hc = t.HC[il] + (own_crit ? s.hvl : 0.0);
+        const double target = s.R - A * (1.0 + 1e-6) - (0.1001 + 1e-7 * s.R);
+        if (!(A < 1e300) || !(hc >= 0.0) || !(hl >= 0.0) || !(target > 0.0) || !(vm < 1e7) || !(s.R < 1e12))
+            return 0;
+        const double e2 = s.vmi - 1e-12, e21 = e2 - 1e-10;
+        int m = 19;
+        if (hc > 0.0) {
+            // hc x / sqrt(1 - x^2 vm^2) <= target  <=>  1 - x vm >= g,  g = 1 / (s1 (s1 + tq)),  tq = target vm / hc
+            const double tq = target * vm / hc;
+            const double s1 = sqrt(1.0 + tq * tq);
+            const double gap = 1.0 / (s1 * (s1 + tq) * vm) - 1e-12;       // x2 - xmid_m may be this small
+            if (gap > 0.0) {
+                const double ratio = e21 / gap;                            // 2^m <= ratio
+                m = ratio >= 2.0 ? ((__double2hiint(ratio) >> 20) & 0x7FF) - 1023 - 2 : 0;   // floor(log2) - 2
+                m = m > 19 ? 19 : m;
+            }
+        }
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2 && m >= 1; ++attempt, --m) {
+            const double x = e2 + ldexp(-e21, -m);                        // the solver's xmid of trip m
+            const double y = x * vm, w = 1.0 - y * y;
+            if (!(w > 1e-6))
+                continue;
+            const double term = hc * x / sqrt(w);
+            if (term * (1.0 + 1e-6) <= target)
+                return m;
+        }
+        return 0;
+    }
+}
+
+// For a lane that has just entered solvebst with f(x1) > 0 (lane_enter_bisection(s, false)): skip the provably idle trips.
+template <typename T>
+__device__ __forceinline__ void lane_skip_idle_trips(const LayerTable<T> &t, Lane<T> &s, int il, T hl)
+{
+    const int m = bisection_skip(t, s, il, hl);
+    if (m >= 1) {
+        const T e2 = s.vmi - T(1e-12), e21 = e2 - T(1e-10);
+        s.dx = ldexp(-e21, -(m + 1));
+        s.xe = e2 + s.dx;
+        s.k = m + 1;
     }
 }
 

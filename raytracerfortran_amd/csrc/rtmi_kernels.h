@@ -34,6 +34,7 @@ struct TraceArgsT {
     int max_nlayers; // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers] (the LDS table is sized for it)
     int allow_skip;  // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
     int *d_status;   // sticky fault word (host-mapped) or NULL: bit 8 = a d_nlayers[m] out of range
+    int skiptab;     // set by the launcher: the layer tables carry the bound of bisection_skip (models of <= 64 interfaces)
 };
 typedef TraceArgsT<double> TraceArgs;
 
@@ -50,6 +51,7 @@ struct FusedArgsT {
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
     int rows;                    // set by the launcher: layer tables with one row per stack height (small models)
+    int skiptab;                 // set by the launcher: the layer tables carry the bound of bisection_skip (<= 64 interfaces)
     int promote_age;             // local waves hand a source to the express waves after this many trips (0 = off)
     int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off)
     const T *d_src_offset;  // [nsrc]

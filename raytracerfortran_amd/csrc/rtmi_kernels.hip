@@ -80,7 +80,10 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
     while (__any(s.st != ST_DONE)) {
         T f, fp;
         eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, s.st != ST_DONE, f, fp);
+        const bool was_init = s.st == ST_INIT;
         lane_advance(s, f, fp);
+        if (was_init && s.skip0 && s.st == ST_BIS)  // solvebst entered with f(x1) > 0: idle trips need not be made
+            lane_skip_idle_trips(t, s, il, z - t.D[il - 1]);
     }
 
     T tt = travel_time(t, s.x, s.nfull, nfull_wave, il, z, active);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
                                            WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr))
         return;
-    const LayerTable<T> t = carve_table(lds, nlayers);
+    const LayerTable<T> t = carve_table(lds, nlayers, false, a.skiptab != 0);
     stage_model(t, a.d_vels + (int64_t)m * a.ld_model, a.d_depths + (int64_t)m * a.ld_model, nlayers);
 
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
@@ -249,12 +252,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
     T z_next = depth_of(0, wib);
-    const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS);
+    const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS, a.skiptab != 0);
     stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
-                                  (RTMI_TABLE_ELEMS(a.nlayers, ROWS) * sizeof(T) + 15) / 16 * 16);  // offset }
+                                  (RTMI_TABLE_ELEMS(a.nlayers, ROWS, a.skiptab) * sizeof(T) + 15) / 16 * 16);  // offset }
     T *rz = rR + slots;                                  // depth             } sorted by descending layer
     T *rp = rz + slots;                                  // p0, later p_final }
     uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                             s.k = 2;
                         } else if (s.skip0) {
                             lane_enter_bisection(s, false);  // f(1e-10) > 0 without evaluating it (lane_setup)
+                            lane_skip_idle_trips(t, s, nl - 1, rz[slot] - t.D[nl - 2]);
                         } else {
                             s.st = ST_BIS0;    // solvebst(1d-10, ...): rp holds x1 = 1e-10
                         }
@@ -995,7 +999,8 @@ static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &args, int nmodels, i
     using namespace rtmi;
     TraceArgsT<T> a = args;
     a.max_nlayers = max_nlayers;  // what the LDS table below is sized for: the kernel checks d_nlayers[m] against it
-    const size_t lds_bytes = RTMI_TABLE_ELEMS(max_nlayers, false) * sizeof(T);
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
+    const size_t lds_bytes = RTMI_TABLE_ELEMS(max_nlayers, false, a.skiptab) * sizeof(T);
     const dim3 grid(grid_x, nmodels, 1), block(RTMI_BLOCK, 1, 1);
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
@@ -1059,7 +1064,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = (RTMI_TABLE_ELEMS(max_nlayers, max_nlayers <= RTMI_ROWS_MAX_NL) * elem_bytes + 15) / 16 * 16;
+    const size_t table = (RTMI_TABLE_ELEMS(max_nlayers, max_nlayers <= RTMI_ROWS_MAX_NL, max_nlayers <= RTMI_SKIP_MAX_NL) * elem_bytes + 15) / 16 * 16;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
                          (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
                          (128 + 128) * sizeof(uint32_t);
@@ -1133,7 +1138,8 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     }
     FusedArgsT<T> a = args;
     a.max_nlayers = max_nlayers;  // what the LDS table is sized for: the kernel checks d_nlayers[m] against it
-    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;  // launch-wide: the layer tables carry one row per stack height
+    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;  // launch-wide: the layer tables carry one row per stack height
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
