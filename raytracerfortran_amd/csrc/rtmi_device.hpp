@@ -1025,8 +1025,8 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 // bound f(xmid_m) > tol (costFunc's sum bounded from above through the table of stage_model, 1e-6 relative and 1e-4
 // absolute margins over the ~1e-10 noise of the computed sums) proves trips 1..m idle, and the source enters the
 // bisection at trip m + 1 with the state those trips would have left: dx = -(x2 - x1) 2^-(m+1) (halvings are exact),
-// xmid = x2 + dx, trip counter m + 1.  m is first estimated in closed form (two trips of slack), then VERIFIED at the
-// solver's own xmid_m; a failed verification just means no skip.  Returns m (0 = none).  Double precision only: in
+// xmid = x2 + dx, trip counter m + 1.  m is first estimated in closed form, then VERIFIED at the solver's own xmid_m
+// (up to three candidates, downwards); a failed verification just means no skip.  Returns m (0 = none).  Double precision only: in
 // single precision the noise of the sums is of the order of tol itself.
 template <typename T>
 __device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane<T> &s, int il, T hl)
@@ -1052,12 +1052,12 @@ __device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane
             const double gap = 1.0 / (s1 * (s1 + tq) * vm) - 1e-12;       // x2 - xmid_m may be this small
             if (gap > 0.0) {
                 const double ratio = e21 / gap;                            // 2^m <= ratio
-                m = ratio >= 2.0 ? ((__double2hiint(ratio) >> 20) & 0x7FF) - 1023 - 2 : 0;   // floor(log2) - 2
+                m = ratio >= 2.0 ? ((__double2hiint(ratio) >> 20) & 0x7FF) - 1023 : 0;   // floor(log2 ratio)
                 m = m > 19 ? 19 : m;
             }
         }
 #pragma unroll 1
-        for (int attempt = 0; attempt < 2 && m >= 1; ++attempt, --m) {
+        for (int attempt = 0; attempt < 3 && m >= 1; ++attempt, --m) {
             const double x = e2 + ldexp(-e21, -m);                        // the solver's xmid of trip m
             const double y = x * vm, w = 1.0 - y * y;
             if (!(w > 1e-6))
