@@ -212,7 +212,7 @@ int rtmi_device_cus(void);
  *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
  *                     fewer than g x tail_group remain queued, 0..4096 (default 256, 0 = off)
  *   "promote_age"     waves 4.. of a workgroup hand a source over to the express waves 0..3 (one per SIMD) once it
- *                     has taken this many evaluation trips, 0..64 (default 8, 0 = off; applies to rounds of at
+ *                     has taken this many evaluation trips, 0..64 (default 5, 0 = off; applies to rounds of at
  *                     least two records per lane)
  *   "diag_fine"       with rtmi_debug_stamps: 1 (default) also takes the per-trip section clocks and counters, which
  *                     slow the solve loop down by about a quarter; 0 keeps to the phase and per-wave clocks

@@ -13,7 +13,7 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
     out = torch.empty(off.size, dtype=torch.float64, device=dev)
     settings = [("m%d r%d a%d" % (m, r, a), dict(refill_min=m, retire_max=r, promote_age=a))
-                for m in (16, 24) for r in (8, 12, 16) for a in (7, 8, 9, 10)]
+                for m in (12, 16, 24) for r in (8, 16) for a in (0, 3, 4, 5, 6, 8)]
     res = {n: [] for n, _ in settings}
     for r in range(7):
         for n, val in settings:
@@ -29,5 +29,5 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     print("N =", N)
     for n, _ in settings:
         a = np.array(res[n]); print("  %-12s median %.4f ms  min %.4f ms" % (n, np.median(a), a.min()))
-    for k, x in dict(refill_min=16, retire_max=12, promote_age=8).items():
+    for k, x in dict(refill_min=16, retire_max=12, promote_age=5).items():
         rt.set_option(k, x)
