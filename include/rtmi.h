@@ -208,11 +208,11 @@ int rtmi_device_cus(void);
  * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
  *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel
  *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
- *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 16)
+ *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 32)
  *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
- *                     fewer than g x tail_group remain queued, 0..4096 (default 256, 0 = off)
+ *                     fewer than g x tail_group remain queued, 0..4096 (default 0 = off)
  *   "promote_age"     waves 4.. of a workgroup hand a source over to the express waves 0..3 (one per SIMD) once it
- *                     has taken this many evaluation trips, 0..64 (default 5, 0 = off; applies to rounds of at
+ *                     has taken this many evaluation trips, 0..64 (default 3, 0 = off; applies to rounds of at
  *                     least two records per lane)
  *   "diag_fine"       with rtmi_debug_stamps: 1 (default) also takes the per-trip section clocks and counters, which
  *                     slow the solve loop down by about a quarter; 0 keeps to the phase and per-wave clocks

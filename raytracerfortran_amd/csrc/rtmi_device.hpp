@@ -1005,6 +1005,22 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     if constexpr (MODE == ADV_ANY) {
         if (initB && s.skip0)  // f(x1) is provably positive: straight to the first midpoint (see lane_setup)
             lane_enter_bisection(s, false);
+        // solvebst left through `fmid < 0` or the jump test: solve() starts at the point just evaluated, so its first
+        // iteration is taken now (see lane_advance_solve)
+        if (bis_done && (neg || (!zero && jump))) {
+            if (small) {
+                s.conv = true;
+                s.st = ST_DONE;
+            } else {
+                T xn = xb2 - q;
+                if (xn > s.vmi)
+                    xn = s.clampv;
+                s.x = xn;
+                s.xe = xn;
+                s.k = 2;
+                s.st = ST_NEWTON;
+            }
+        }
     }
     if constexpr (MODE == ADV_NO_INIT) {
         const bool b0 = (st == ST_BIS0);  // untouched by everything above
@@ -1130,12 +1146,22 @@ __device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
         const bool done = zero || jump || small || s.k == 20;  // (:375, :388, :394, maxiter)
         const T xb2 = (!zero && jump) ? s.xe : xb1;            // (:388-391) x = xmid; exit
         const T dxh = s.dx * T(0.5);         // dx = dx*0.5; xmid = x + dx (:368-369)
+        // solvebst returns x = xmid whenever it leaves through `fmid < 0` or the jump test; solve(x) then STARTS by
+        // evaluating f and f' at that very point (:269-294) -- the values this trip has just computed, from the same
+        // operands.  Its first iteration is therefore taken here (as lane_advance_init does for solve(p0)): one
+        // evaluation less for nearly every bisection source.
+        const bool fuse = done && (neg || (!zero && jump));
+        T xnew = s.xe - q;                   // x = x - deltax (:298)
+        if (xnew > s.vmi)
+            xnew = s.clampv;                 // (:299-304)
+        const bool f_conv = fuse && small, f_go = fuse && !small;
         s.xb = xb2;
         s.dx = done ? s.dx : dxh;
-        s.xe = done ? xb2 : xb2 + dxh;
-        s.x = done ? xb2 : s.x;
-        s.k = done ? 1 : s.k + 1;
-        s.st = done ? ST_NEWTON : ST_BIS;
+        s.xe = f_go ? xnew : (done ? xb2 : xb2 + dxh);
+        s.x = f_go ? xnew : (done ? xb2 : s.x);
+        s.k = f_go ? 2 : (done ? 1 : s.k + 1);
+        s.conv = f_conv ? true : s.conv;     // (:288)
+        s.st = f_conv ? ST_DONE : (done ? ST_NEWTON : ST_BIS);
     } else if (st == ST_NEWTON) {
         T xnew = s.x - q;                    // x = x - deltax (:298)
         if (xnew > s.vmi)

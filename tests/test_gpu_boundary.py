@@ -68,7 +68,7 @@ def test_two_threads_call_dff_concurrently(rt, O):
     def knobs():
         while not stop.is_set():
             rt.set_option("refill_min", 8)
-            rt.set_option("refill_min", 16)
+            rt.set_option("refill_min", 32)
 
     k = threading.Thread(target=knobs)
     k.start()
@@ -79,7 +79,7 @@ def test_two_threads_call_dff_concurrently(rt, O):
     finally:
         stop.set()
         k.join()
-        rt.set_option("refill_min", 16)
+        rt.set_option("refill_min", 32)
 
 
 @pytest.mark.parametrize("n", [4097, 262144, 262145, 1_000_000])
