@@ -249,7 +249,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         // only orders the work, no result depends on it.
         // The table costs O(nlayers^2) operations per workgroup (approximate single-precision reciprocal and
         // reciprocal square root: a few instructions per pair of layers).
-        const bool hint_unused = std::is_same<T, double>::value && t.SA;  // see trip_class
+        const bool hint_unused = t.SA != nullptr;  // see trip_class
         for (int il = 1 + (int)threadIdx.x; il <= nlayers && !hint_unused; il += blockDim.x) {
             if (nlayers > RTMI_HINT_MAX_NL) {
                 // very deep models: one class for all bisection sources (measured at 1024 interfaces: ordering by
@@ -277,35 +277,39 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             t.PH[il] = j < il ? t.H[j] : T(0.0);
         }
     }
-    if constexpr (std::is_same<T, double>::value) {
+    {
         // The bound behind bisection_skip.  For the stack of a source in layer il (fastest velocity vmax, vmi = 1/vmax)
         // and any x <= vmi, a layer slower than vmax contributes at most its term at x = vmi,
         // H V vmi / sqrt(1 - vmi^2 V^2); the layers AT vmax contribute (sum of their H V) x / sqrt(1 - x^2 vmax^2).
-        // Approximate arithmetic (v_rsq_f64 + one Newton step, ~1e-9 relative) is enough: the bound is used with a
-        // 1e-6 margin and decides only which evaluations need not be made, never a value.  +Inf = "no bound" (negative
-        // thicknesses, unsorted interfaces, too many layers).
+        // Approximate arithmetic (v_rsq + one Newton step) is enough: the bound is used with a margin (1e-6 relative in
+        // double, 1e-4 in single precision) and decides only which evaluations need not be made, never a value.
+        // +Inf = "no bound" (negative thicknesses, unsorted interfaces).
         const bool usable = t.HVOK[nlayers] != T(0.0);
         for (int il = 1 + (int)threadIdx.x; il <= nlayers && t.SA; il += blockDim.x) {
-            double sa = 0.0, hc = 0.0, sc = 0.0;
+            T sa = T(0.0), hc = T(0.0), sc = T(0.0);
             if (!usable) {
-                sa = INFINITY;
+                sa = T(INFINITY);
             } else {
-                const double vmax = t.VMAX[il], vmi = div_ieee(1.0, vmax);
+                const T vmax = t.VMAX[il], vmi = div_ieee(T(1.0), vmax);
                 for (int i = 0; i <= il; ++i) {
-                    const double vi = t.V[i];
-                    const double hv = i < il ? t.HV[i] : 1.0;      // own layer: coefficient of its thickness hl times ...
-                    const double vfac = i < il ? 1.0 : vi;          // ... its velocity
-                    if (i < il && !(t.H[i] >= 0.0))
-                        sa = INFINITY;
+                    const T vi = t.V[i];
+                    const T hv = i < il ? t.HV[i] : T(1.0);      // own layer: coefficient of its thickness hl times ...
+                    const T vfac = i < il ? T(1.0) : vi;          // ... its velocity
+                    if (i < il && !(t.H[i] >= T(0.0)))
+                        sa = T(INFINITY);
                     if (vi >= vmax) {
                         if (i < il)
                             hc += hv;
                         continue;
                     }
-                    const double y = vmi * vi, w = 1.0 - y * y;
-                    double r = __builtin_amdgcn_rsq(w);
-                    r = r * (1.5 - 0.5 * w * r * r);
-                    const double term = hv * vfac * vmi * r;
+                    const T y = vmi * vi, w = T(1.0) - y * y;
+                    T r;
+                    if constexpr (std::is_same<T, double>::value)
+                        r = __builtin_amdgcn_rsq(w);
+                    else
+                        r = __builtin_amdgcn_rsqf(w);
+                    r = r * (T(1.5) - T(0.5) * w * r * r);
+                    const T term = hv * vfac * vmi * r;
                     if (i < il)
                         sa += term;
                     else
@@ -328,10 +332,10 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
 template <typename T>
 __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T z)
 {
-    // Models that carry the bound of bisection_skip (double precision, <= RTMI_SKIP_MAX_NL interfaces) enter the
+    // Models that carry the bound of bisection_skip (<= RTMI_SKIP_MAX_NL interfaces) enter the
     // bisection a trip or two before it ends, whatever the geometry: one class (measured: -9 % on a tempering slot
     // against the three classes below, which sort by the trips that are no longer made).
-    if (std::is_same<T, double>::value && t.SA)
+    if (t.SA)
         return RTMI_TRIP_CLASSES - 1;
     const T hl = z - t.D[il - 1];
     const T num = R - (t.PA[il] + hl * t.PC[il]);
@@ -1053,43 +1057,45 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
 template <typename T>
 __device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane<T> &s, int il, T hl)
 {
-    if constexpr (!std::is_same<T, double>::value) {
+    // margins: relative on the bound's own (approximate) arithmetic, absolute over the noise of the solver's computed
+    // sum -- ~(n + 4) ulp of R + sum, i.e. 1e-10 in double but up to 1e-5 R in single precision for n <= 64 terms
+    constexpr bool DBL = std::is_same<T, double>::value;
+    const T relm = DBL ? T(1e-6) : T(1e-4);
+    if (!t.SA)
         return 0;
-    } else {
-        if (!t.SA)
-            return 0;
-        const double vm = t.VMAX[il];
-        const bool own_crit = t.V[il] >= vm;
-        const double A = t.SA[il] + (own_crit ? 0.0 : hl * t.SC[il]);
-        const double hc = t.HC[il] + (own_crit ? s.hvl : 0.0);
-        const double target = s.R - A * (1.0 + 1e-6) - (0.1001 + 1e-7 * s.R);
-        if (!(A < 1e300) || !(hc >= 0.0) || !(hl >= 0.0) || !(target > 0.0) || !(vm < 1e7) || !(s.R < 1e12))
-            return 0;
-        const double e2 = s.vmi - 1e-12, e21 = e2 - 1e-10;
-        int m = 19;
-        if (hc > 0.0) {
-            // hc x / sqrt(1 - x^2 vm^2) <= target  <=>  1 - x vm >= g,  g = 1 / (s1 (s1 + tq)),  tq = target vm / hc
-            const double tq = target * vm / hc;
-            const double s1 = sqrt(1.0 + tq * tq);
-            const double gap = 1.0 / (s1 * (s1 + tq) * vm) - 1e-12;       // x2 - xmid_m may be this small
-            if (gap > 0.0) {
-                const double ratio = e21 / gap;                            // 2^m <= ratio
-                m = ratio >= 2.0 ? ((__double2hiint(ratio) >> 20) & 0x7FF) - 1023 : 0;   // floor(log2 ratio)
-                m = m > 19 ? 19 : m;
-            }
-        }
-#pragma unroll 1
-        for (int attempt = 0; attempt < 3 && m >= 1; ++attempt, --m) {
-            const double x = e2 + ldexp(-e21, -m);                        // the solver's xmid of trip m
-            const double y = x * vm, w = 1.0 - y * y;
-            if (!(w > 1e-6))
-                continue;
-            const double term = hc * x / sqrt(w);
-            if (term * (1.0 + 1e-6) <= target)
-                return m;
-        }
+    const T vm = t.VMAX[il];
+    const bool own_crit = t.V[il] >= vm;
+    const T A = t.SA[il] + (own_crit ? T(0.0) : hl * t.SC[il]);
+    const T hc = t.HC[il] + (own_crit ? s.hvl : T(0.0));
+    const T target = s.R - A * (T(1.0) + relm) - (T(0.1001) + (DBL ? T(1e-7) : T(3e-5)) * s.R);
+    if (!(A < T(1e30)) || !(hc >= T(0.0)) || !(hl >= T(0.0)) || !(target > T(0.0)) || !(vm < T(1e7)) || !(s.R < T(1e12)))
         return 0;
+    const T e2 = s.vmi - T(1e-12), e21 = e2 - T(1e-10);   // as lane_enter_bisection
+    int m = 19;
+    if (hc > T(0.0)) {
+        // hc x / sqrt(1 - x^2 vm^2) <= target  <=>  1 - x vm >= g,  g = 1 / (s1 (s1 + tq)),  tq = target vm / hc
+        const T tq = target * vm / hc;
+        const T s1 = sqrt(T(1.0) + tq * tq);
+        const T gap = T(1.0) / (s1 * (s1 + tq) * vm) - T(1e-12);       // x2 - xmid_m may be this small
+        if (gap > T(0.0)) {
+            const T ratio = e21 / gap;                                  // 2^m <= ratio
+            int ex;
+            (void)frexp(ratio, &ex);                                    // ratio = f 2^ex, f in [0.5, 1): floor(log2) = ex - 1
+            m = ratio >= T(2.0) ? ex - 1 : 0;
+            m = m > 19 ? 19 : m;
+        }
     }
+#pragma unroll 1
+    for (int attempt = 0; attempt < 3 && m >= 1; ++attempt, --m) {
+        const T x = e2 + ldexp(-e21, -m);                               // the solver's xmid of trip m
+        const T y = x * vm, w = T(1.0) - y * y;
+        if (!(w > (DBL ? T(1e-6) : T(1e-3))))
+            continue;
+        const T term = hc * x / sqrt(w);
+        if (term * (T(1.0) + relm) <= target)
+            return m;
+    }
+    return 0;
 }
 
 // For a lane that has just entered solvebst with f(x1) > 0 (lane_enter_bisection(s, false)): skip the provably idle trips.
