@@ -12,8 +12,8 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     v, d, off, dep = bench.c2_workload(N)
     dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
     out = torch.empty(off.size, dtype=torch.float64, device=dev)
-    settings = [("m%d r%d a%d t%d" % (m, r, a, tg), dict(refill_min=m, retire_max=r, promote_age=a, tail_group=tg))
-                for m in (16, 32, 48) for r in (12,) for a in (3, 4) for tg in (0, 256)]
+    settings = [("w%d m%d a%d" % (w, m, a), dict(waves_per_simd=w, refill_min=m, promote_age=a))
+                for w in (2, 3, 4, 5, 6, 8) for m in (16, 32) for a in (3,)]
     res = {n: [] for n, _ in settings}
     for r in range(7):
         for n, val in settings:
@@ -29,5 +29,5 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     print("N =", N)
     for n, _ in settings:
         a = np.array(res[n]); print("  %-12s median %.4f ms  min %.4f ms" % (n, np.median(a), a.min()))
-    for k, x in dict(refill_min=32, retire_max=12, promote_age=3, tail_group=0).items():
+    for k, x in dict(refill_min=32, retire_max=12, promote_age=3, tail_group=0, waves_per_simd=4).items():
         rt.set_option(k, x)

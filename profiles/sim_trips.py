@@ -3,7 +3,7 @@ evaluated, (ii) the provably idle bisection trips are skipped (ideal bound) and 
 taken in the trip in which solvebst leaves: a numpy restatement, for the histogram only (the kernels are checked
 against the oracle)."""
 import numpy as np, sys
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracerfortran_amd.synthetic import c2_workload
 n=100000
 v,d,off,dep=c2_workload(n)

@@ -1071,14 +1071,33 @@ __device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane
     if (!(A < T(1e30)) || !(hc >= T(0.0)) || !(hl >= T(0.0)) || !(target > T(0.0)) || !(vm < T(1e7)) || !(s.R < T(1e12)))
         return 0;
     const T e2 = s.vmi - T(1e-12), e21 = e2 - T(1e-10);   // as lane_enter_bisection
+    // approximate reciprocal / reciprocal square root, one Newton step each (~1e-9 relative in double, 1e-6 in single
+    // precision: far inside the margins above; the bound decides which evaluations are skipped, never a value)
+    auto rcp = [](T a) {
+        T r;
+        if constexpr (DBL)
+            r = __builtin_amdgcn_rcp(a);
+        else
+            r = __builtin_amdgcn_rcpf(a);
+        return r * (T(2.0) - a * r);
+    };
+    auto rsq = [](T a) {
+        T r;
+        if constexpr (DBL)
+            r = __builtin_amdgcn_rsq(a);
+        else
+            r = __builtin_amdgcn_rsqf(a);
+        return r * (T(1.5) - T(0.5) * a * r * r);
+    };
     int m = 19;
     if (hc > T(0.0)) {
         // hc x / sqrt(1 - x^2 vm^2) <= target  <=>  1 - x vm >= g,  g = 1 / (s1 (s1 + tq)),  tq = target vm / hc
-        const T tq = target * vm / hc;
-        const T s1 = sqrt(T(1.0) + tq * tq);
-        const T gap = T(1.0) / (s1 * (s1 + tq) * vm) - T(1e-12);       // x2 - xmid_m may be this small
+        const T tq = target * vm * rcp(hc);
+        const T q2 = T(1.0) + tq * tq;
+        const T s1 = q2 * rsq(q2);
+        const T gap = rcp(s1 * (s1 + tq) * vm) - T(1e-12);             // x2 - xmid_m may be this small
         if (gap > T(0.0)) {
-            const T ratio = e21 / gap;                                  // 2^m <= ratio
+            const T ratio = e21 * rcp(gap);                             // 2^m <= ratio (estimate: verified below)
             int ex;
             (void)frexp(ratio, &ex);                                    // ratio = f 2^ex, f in [0.5, 1): floor(log2) = ex - 1
             m = ratio >= T(2.0) ? ex - 1 : 0;
@@ -1091,7 +1110,7 @@ __device__ __forceinline__ int bisection_skip(const LayerTable<T> &t, const Lane
         const T y = x * vm, w = T(1.0) - y * y;
         if (!(w > (DBL ? T(1e-6) : T(1e-3))))
             continue;
-        const T term = hc * x / sqrt(w);
+        const T term = hc * x * rsq(w);
         if (term * (T(1.0) + relm) <= target)
             return m;
     }
