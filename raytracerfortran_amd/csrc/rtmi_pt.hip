@@ -9,7 +9,7 @@
 // Here the chains of one process (one GPU) advance in lock-step and NOTHING of a sweep runs on the host:
 //   * chain state (k, node depths and velocities, sigma, logL, SS, beta, the position of the chain's random stream)
 //     lives in HBM for the lifetime of the handle;
-//   * a proposal slot is two launches on one stream: pt_step_kernel (one thread per chain: accept/reject the
+//   * a proposal slot is two launches on one stream: pt_step_kernel (one lane group per chain: accept/reject the
 //     previous slot from the residual sums the likelihood launch left behind, then draw this slot's proposal, check
 //     CHECKBOUNDS and write the proposed model as a row of the batch) and the batched likelihood launch of
 //     rtmi_kernels.hip over the handle's resident sources (rows of chains without a valid proposal are marked
@@ -67,53 +67,49 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
         dst[i] = src[i];
 }
 
-// Per-thread working arrays of the sweep kernels live in LDS, not in private (scratch) memory: the rules index them
-// dynamically (insertion sort of the nodes), and a scratch access costs a trip to HBM -- a one-thread-per-chain kernel
-// is nothing but a chain of such latencies.  Layout: thread t owns [t * stride, (t + 1) * stride).
+// Working arrays of pt_pack_current_kernel (one thread per chain) live in LDS, not in private (scratch) memory: the
+// rules index them dynamically.  Layout: thread t owns [t * stride, (t + 1) * stride).
 #define PT_BLOCK 64
+#define PT_STEP_THREADS 256
 
-// One thread per chain: [decide the previous slot] [sigma move] [propose the next slot].
-// LDS per block: the chains' current and proposed nodes (staged cooperatively, coalesced, in ONE round trip to HBM
-// together with the threads' scalar state), the depth-order scratch and the Poisson table.
-__global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
+// pt_step_kernel: [decide the previous slot] [sigma move] [propose the next slot], one GROUP of G lanes per chain
+// (G = 16, 32 or 64 >= K, groups never straddle a wave).  Lane i of a group holds node i of its chain in registers;
+// everything scalar (the residual sum, the likelihood, the random draws, the acceptance tests) is computed by all G
+// lanes alike -- in SIMD that costs what one lane costs and needs no broadcast -- and everything per node (the bound
+// checks, the depth order, packing the model row, committing an accepted proposal) is one step wide instead of a loop
+// of dependent LDS round trips: the depth order is a rank count over lane shuffles (stable: ties keep node order,
+// as the insertion sort of rtmi_pt_rules.h::sorted_order), CHECKBOUNDS' spacing test reads the predecessor in depth
+// from the lane that holds rank - 1.  A one-thread-per-chain version of the same rules spent 60 % of its 12 us in the
+// sort and the packing loops (profiles/r02k/pt_step_phases.txt).  The rules and the random streams are unchanged:
+// chains advance bit for bit as before (tests/test_tempering.py compares with the host rules).
+template <int G>
+__global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
 {
-    extern __shared__ __attribute__((aligned(16))) double pt_lds[];
+    constexpr int CPB = PT_STEP_THREADS / G;  // chains per block
+    const int i = threadIdx.x % G;            // the node this lane holds
+    const int c = blockIdx.x * CPB + threadIdx.x / G;
+    if (c >= d.nchains)
+        return;  // whole groups leave together; there is no block-level barrier below
+    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gbase;
     const int K = d.K;
-    double *l_cz = pt_lds, *l_cv = l_cz + PT_BLOCK * K, *l_pz = l_cv + PT_BLOCK * K, *l_pv = l_pz + PT_BLOCK * K;
-    double *l_lpk = l_pv + PT_BLOCK * K;                                   // [K + 2]
-    int *l_ord = reinterpret_cast<int *>(l_lpk + K + 2);                    // [PT_BLOCK][K]
-    const int c0 = blockIdx.x * PT_BLOCK;
-    const int nloc = d.nchains - c0 < PT_BLOCK ? d.nchains - c0 : PT_BLOCK;
-    for (int i = threadIdx.x; i < nloc * K; i += PT_BLOCK) {
-        l_cz[i] = d.z[(size_t)c0 * K + i];
-        l_cv[i] = d.v[(size_t)c0 * K + i];
-        l_pz[i] = d.pz[(size_t)c0 * K + i];
-        l_pv[i] = d.pv[(size_t)c0 * K + i];
-    }
-    for (int i = threadIdx.x; i < K + 2; i += PT_BLOCK)
-        l_lpk[i] = d.logpk[i];
-    const int c = c0 + threadIdx.x;
-    const bool mine = c < d.nchains;
-    const int cc = mine ? c : c0;  // threads without a chain shadow the block's first one and write nothing
     const rtmi_pt_prior &p = d.pr;
-    int k = d.k[cc];
-    const int act = d.pactive[cc];
-    const int pk = d.pk[cc];
-    const unsigned long long ctr0 = d.ctr[cc];
-    double sd = d.sd[cc], logL = d.logL[cc], ss = d.ss[cc];
-    const double beta = d.beta[cc], plp = d.plp[cc];
+    const bool lead = i == 0;
+    const size_t row = (size_t)c * K + (i < K ? i : 0);
+    // ---- one round trip to HBM: this lane's node (current and proposed), the chain's scalars, the Poisson table ----
+    double zi = d.z[row], vi = d.v[row];
+    const double pzi = d.pz[row], pvi = d.pv[row];
+    const double lpk_lo = d.logpk[i < K + 2 ? i : K + 1], lpk_hi = d.logpk[i + G < K + 2 ? i + G : K + 1];
+    int k = d.k[c];
+    const int act = d.pactive[c];
+    const int pk = d.pk[c];
+    const unsigned long long ctr0 = d.ctr[c];
+    double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
+    const double beta = d.beta[c], plp = d.plp[c];
     double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
     if (decide != PT_NONE && act != 0)
-        for (int i = 0; i < d.gx; ++i)
-            part = part + d.partial[(size_t)cc * d.gx + i];
-    __syncthreads();
-    if (!mine)
-        return;
-    double *qz = l_cz + (size_t)threadIdx.x * K, *qv = l_cv + (size_t)threadIdx.x * K;
-    const double *lz = l_pz + (size_t)threadIdx.x * K, *lv = l_pv + (size_t)threadIdx.x * K;
-    int *ord = l_ord + (size_t)threadIdx.x * K;
-    double *zc = d.z + (size_t)c * K, *vc = d.v + (size_t)c * K;
-    double *pz = d.pz + (size_t)c * K, *pv = d.pv + (size_t)c * K;
+        for (int j = 0; j < d.gx; ++j)
+            part = part + d.partial[(size_t)c * d.gx + j];
     long long *st = d.stats + (size_t)c * 8;
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
 
@@ -127,22 +123,26 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
             double lr = plp + (logl_new - logL) * beta;
             if (lr > 50.0)
                 lr = 50.0;
-            st[2 * decide + 1] += 1;
+            if (lead)
+                st[2 * decide + 1] += 1;
             if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
                 k = pk;
                 ss = part;
                 logL = logl_new;
-                st[2 * decide] += 1;
-                d.k[c] = k;
-                for (int i = 0; i < k; ++i) {  // the proposal becomes the state: LDS copy and HBM
-                    qz[i] = lz[i];
-                    qv[i] = lv[i];
-                    zc[i] = lz[i];
-                    vc[i] = lv[i];
+                if (lead) {
+                    st[2 * decide] += 1;
+                    d.k[c] = k;
+                }
+                if (i < k) {  // the proposal becomes the state
+                    zi = pzi;
+                    vi = pvi;
+                    d.z[row] = zi;
+                    d.v[row] = vi;
                 }
             }
         }
-        d.pactive[c] = 0;
+        if (lead)
+            d.pactive[c] = 0;
     }
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
         if (R::philox_uniform(rng) >= 0.10) {
             const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
             const double sd_new = sd + step * R::philox_normal(rng);
-            st[5] += 1;
+            if (lead)
+                st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
                 const double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
                 double lr = (logl_new - logL) * beta;
@@ -159,77 +160,135 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_step_kernel(PtDev d, int decide, 
                 if (!(R::philox_uniform(rng) >= exp(lr))) {
                     sd = sd_new;
                     logL = logl_new;
-                    st[4] += 1;
+                    if (lead)
+                        st[4] += 1;
                 }
             }
         }
     }
-    d.sd[c] = sd;
-    d.logL[c] = logL;
-    d.ss[c] = ss;
+    if (lead) {
+        d.sd[c] = sd;
+        d.logL[c] = logL;
+        d.ss[c] = ss;
+    }
+    if (propose == PT_NONE) {
+        if (lead)
+            d.ctr[c] = rng.index;
+        return;  // launch-uniform
+    }
 
     // ---- proposal of the next slot --------------------------------------------------------------------------------
-    if (propose != PT_NONE) {
-        int qk = k;
-        double lp = 0.0;
-        bool have = false;
-        if (propose == PT_BD) {
-            // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
-            if (p.kmin != p.kmax) {
-                const double u = R::philox_uniform(rng);
-                int move;
-                if (k == p.kmax)
-                    move = (u <= 0.3333) ? 2 : 0;
-                else if (k == p.kmin)
-                    move = (u <= 0.3333) ? 1 : 0;
-                else
-                    move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
-                if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
-                    qz[k] = (p.hmx - p.hmin) * R::philox_uniform(rng);
-                    qv[k] = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
-                    qk = k + 1;
-                    lp = l_lpk[k + 1] - l_lpk[k];
-                    have = true;
-                } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
-                    int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
-                    if (idel > k - 1)
-                        idel = k - 1;
-                    for (int i = idel; i + 1 < k; ++i) {
-                        qz[i] = qz[i + 1];
-                        qv[i] = qv[i + 1];
-                    }
-                    qk = k - 1;
-                    lp = l_lpk[k - 1] - l_lpk[k];
-                    have = true;
-                }
-            }
-        } else if (ivo < k) {
-            // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
-            const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
-            const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
-            if (ipar == 0)
-                qz[ivo] += step;
+    // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the chain-dependent branches.
+    const int up = lane + 1 < 64 ? lane + 1 : 63;
+    const double z_up = __shfl(zi, up, 64), v_up = __shfl(vi, up, 64);  // node i + 1 (death shifts the nodes down)
+    const int kc = k < 1 ? 1 : k;
+    const double lpk_k = kc < G ? __shfl(lpk_lo, gbase + (kc & (G - 1)), 64) : __shfl(lpk_hi, gbase + ((kc - G) & (G - 1)), 64);
+    const double lpk_kp = kc + 1 < G ? __shfl(lpk_lo, gbase + ((kc + 1) & (G - 1)), 64)
+                                     : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
+    const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
+                                     : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
+    int qk = k;
+    double lp = 0.0;
+    bool have = false;
+    if (propose == PT_BD) {
+        // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
+        if (p.kmin != p.kmax) {
+            const double u = R::philox_uniform(rng);
+            int move;
+            if (k == p.kmax)
+                move = (u <= 0.3333) ? 2 : 0;
+            else if (k == p.kmin)
+                move = (u <= 0.3333) ? 1 : 0;
             else
-                qv[ivo] += step;
-            have = true;
-        }
-        int nl = 0;
-        if (have) {
-            if (R::inside_bounds(qz, qv, qk, p, ord)) {
-                nl = R::pack_model(qz, qv, qk, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
-                load_nodes(qz, pz, qk);
-                load_nodes(qv, pv, qk);
-                d.pk[c] = qk;
-                d.plp[c] = lp;
-                d.pactive[c] = 1;
-                st[6] += 1;  // a model that goes through the likelihood
-            } else {
-                st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)
+                move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
+            if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
+                const double zn = (p.hmx - p.hmin) * R::philox_uniform(rng);
+                const double vn = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
+                if (i == k) {
+                    zi = zn;
+                    vi = vn;
+                }
+                qk = k + 1;
+                lp = lpk_kp - lpk_k;
+                have = true;
+            } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
+                int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
+                if (idel > k - 1)
+                    idel = k - 1;
+                if (i >= idel && i + 1 < k) {
+                    zi = z_up;
+                    vi = v_up;
+                }
+                qk = k - 1;
+                lp = lpk_km - lpk_k;
+                have = true;
             }
         }
-        d.NL[c] = nl;
+    } else if (ivo < k) {
+        // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
+        const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
+        const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
+        if (i == ivo) {
+            if (ipar == 0)
+                zi += step;
+            else
+                vi += step;
+        }
+        have = true;
     }
-    d.ctr[c] = rng.index;
+    // CHECKBOUNDS (prjmh_temper_rf.f90:1639-1679; rtmi_pt_rules.h::inside_bounds) over the qk proposed nodes
+    const bool in = have && i < qk;
+    bool bad = in && (vi < p.vmin || vi > p.vmax);
+    bad = bad || (in && qk > 1 && i >= 1 && (zi < 0.0 || zi > p.hmx));
+    int r = 0;  // rank of this node in depth (stable)
+    for (int j = 0; j < K; ++j) {
+        const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
+        r += (in && j < qk && (zj < zi || (zj == zi && j < i))) ? 1 : 0;
+    }
+    double prev = 0.0;  // the node above in depth; the rule measures the second node's spacing from 0
+    for (int j = 0; j < K; ++j) {
+        const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
+        const int rj = __shfl(r, gbase + (j & (G - 1)), 64);
+        if (j < qk && r >= 2 && rj == r - 1)
+            prev = zj;
+    }
+    bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
+    const bool ok = have && (__ballot(bad) & gmask) == 0ull;
+    int nl = 0;
+    if (ok) {
+        // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision
+        double *Vr = d.V + (size_t)c * d.ld_model, *Dr = d.D + (size_t)c * d.ld_model;
+        if (qk == 1) {
+            if (lead) {
+                Vr[0] = Vr[1] = vi;
+                Dr[0] = 9999.9;
+            }
+            nl = 1;
+        } else {
+            if (in) {
+                Vr[r] = vi;
+                if (r >= 1)
+                    Dr[r - 1] = zi;
+            }
+            nl = qk - 1;
+        }
+        if (in) {
+            d.pz[row] = zi;
+            d.pv[row] = vi;
+        }
+        if (lead) {
+            d.pk[c] = qk;
+            d.plp[c] = lp;
+            d.pactive[c] = 1;
+            st[6] += 1;  // a model that goes through the likelihood
+        }
+    } else if (have && lead) {
+        st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)
+    }
+    if (lead) {
+        d.NL[c] = nl;
+        d.ctr[c] = rng.index;
+    }
 }
 
 // The current state of every chain as batch rows (rtmi_pt_evaluate).
@@ -357,9 +416,22 @@ struct rtmi_pt {
 namespace {
 
 int blocks_for(int n) { return (n + PT_BLOCK - 1) / PT_BLOCK; }
-size_t step_lds(const rtmi_pt *h)
+size_t pack_lds(const rtmi_pt *h)
 {
-    return (size_t)PT_BLOCK * (size_t)h->K * (4 * sizeof(double) + sizeof(int)) + ((size_t)h->K + 2) * sizeof(double);
+    return (size_t)PT_BLOCK * (size_t)h->K * (2 * sizeof(double) + sizeof(int));
+}
+// pt_step_kernel with the narrowest lane group that holds K nodes
+void launch_step(rtmi_pt *h, int decide, int sigma, int propose, int ivo, int ipar)
+{
+    const int G = h->K <= 16 ? 16 : (h->K <= 32 ? 32 : 64);
+    const int cpb = PT_STEP_THREADS / G;
+    const dim3 g((h->nchains + cpb - 1) / cpb), b(PT_STEP_THREADS);
+    if (G == 16)
+        hipLaunchKernelGGL(pt_step_kernel<16>, g, b, 0, h->stream, h->d, decide, sigma, propose, ivo, ipar);
+    else if (G == 32)
+        hipLaunchKernelGGL(pt_step_kernel<32>, g, b, 0, h->stream, h->d, decide, sigma, propose, ivo, ipar);
+    else
+        hipLaunchKernelGGL(pt_step_kernel<64>, g, b, 0, h->stream, h->d, decide, sigma, propose, ivo, ipar);
 }
 
 int launch_likelihood(rtmi_pt *h)
@@ -379,8 +451,7 @@ int launch_likelihood(rtmi_pt *h)
 // One sweep with `nslots_k` node slots enqueued on the handle's stream (directly, or into a capture).
 int enqueue_sweep(rtmi_pt *h, int nslots_k)
 {
-    const dim3 g(blocks_for(h->nchains)), b(64);
-    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, (int)PT_NONE, 0, (int)PT_BD, 0, 0);
+    launch_step(h, PT_NONE, 0, PT_BD, 0, 0);
     int rc = launch_likelihood(h);
     if (rc)
         return rc;
@@ -389,13 +460,13 @@ int enqueue_sweep(rtmi_pt *h, int nslots_k)
         for (int ipar = 0; ipar < 2; ++ipar) {
             if (ivo == 0 && ipar == 0)
                 continue;  // the surface node's depth is not a parameter (:727)
-            hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, prev, 0, (int)PT_MH, ivo, ipar);
+            launch_step(h, prev, 0, PT_MH, ivo, ipar);
             rc = launch_likelihood(h);
             if (rc)
                 return rc;
             prev = PT_MH;
         }
-    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, prev, 1, (int)PT_NONE, 0, 0);
+    launch_step(h, prev, 1, PT_NONE, 0, 0);
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
@@ -493,14 +564,11 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     if (hipSetDevice(c.device) != hipSuccess)
         return nullptr;
     {
-        // the sweep kernels keep K doubles x 2 + K ints per thread in LDS: above 64 KiB that needs the opt-in
-        const size_t need = (size_t)PT_BLOCK * (size_t)prior->kmax * (4 * sizeof(double) + sizeof(int)) +
-                            ((size_t)prior->kmax + 2) * sizeof(double);
+        // pt_pack_current_kernel keeps K doubles x 2 + K ints per thread in LDS: above 64 KiB that needs the opt-in
+        const size_t need = (size_t)PT_BLOCK * (size_t)prior->kmax * (2 * sizeof(double) + sizeof(int));
         if (need > 64 * 1024 &&
-            (hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)need) != hipSuccess ||
-             hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_pack_current_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_pack_current_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
             fail(RTMI_ERR_HIP, "rtmi_pt_create: cannot reserve %zu bytes of LDS for the sweep kernels", need);
             return nullptr;
         }
@@ -703,11 +771,11 @@ int rtmi_pt_evaluate(rtmi_pt *h)
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     const dim3 g(blocks_for(h->nchains)), b(64);
-    hipLaunchKernelGGL(pt_pack_current_kernel, g, b, step_lds(h), h->stream, h->d);
+    hipLaunchKernelGGL(pt_pack_current_kernel, g, b, pack_lds(h), h->stream, h->d);
     int rc = launch_likelihood(h);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(pt_step_kernel, g, b, step_lds(h), h->stream, h->d, (int)PT_EVAL, 0, (int)PT_NONE, 0, 0);
+    launch_step(h, PT_EVAL, 0, PT_NONE, 0, 0);
     HIP_TRY(hipGetLastError());
     h->launches += 1;
     h->models += h->nchains;
