@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/ab_x.py N [N ...] -- tail_group x promote_age x retire_max at several source counts (interleaved A/B)."""
+"""profiles/ab_x.py N [N ...] -- refill_min x promote_age x retire_max at several source counts (interleaved A/B)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,8 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     v, d, off, dep = bench.c2_workload(N)
     dv, dd, do, dz = (torch.tensor(x, device=dev) for x in (v, d, off, dep))
     out = torch.empty(off.size, dtype=torch.float64, device=dev)
-    settings = [("w%d m%d a%d" % (w, m, a), dict(waves_per_simd=w, refill_min=m, promote_age=a))
-                for w in (2, 3, 4, 5, 6, 8) for m in (16, 32) for a in (3,)]
+    settings = [("m%d a%d r%d" % (m, a, r), dict(refill_min=m, promote_age=a, retire_max=r))
+                for m in (24, 32, 40) for a in (2, 3, 4) for r in (8, 12, 16)]
     res = {n: [] for n, _ in settings}
     for r in range(7):
         for n, val in settings:

@@ -210,7 +210,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_CLASSES 4             // RTMI_TRIP_CLASSES classes of bisection sources + the Newton-only class
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
-#define RTMI_RK_DONE 0x40000000u      // rk: finished by its first evaluation (or p0 is NaN): not in the solve order
+#define RTMI_RK_DONE 0x40000000u      // rk: p_final is in rp (set by the first evaluation, or when the solve loop finishes the source)
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
@@ -463,8 +463,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                 }
                 if (lane == 0)
                     ch_cnt[q0 >> 6] = w0;
+                // finished records (class 7) follow the solve order in order[]: the time pass walks all of it
+                const unsigned long long fin = __ballot(valid && !todo);
                 if (valid)
-                    tnl[q] = todo ? ((uint32_t)cls | ((uint32_t)__popcll(mine & lt_mask) << 3)) : 0xFFFFFFFFu;
+                    tnl[q] = todo ? ((uint32_t)cls | ((uint32_t)__popcll(mine & lt_mask) << 3))
+                                  : (7u | ((uint32_t)__popcll(fin & lt_mask) << 3));
             }
         }
         __syncthreads();
@@ -510,8 +513,18 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             const uint32_t v = q < nq ? tnl[q] : 0xFFFFFFFFu;  // class | rank within (chunk, class) << 3
             if (v != 0xFFFFFFFFu) {
                 const int cls = (int)(v & 7u);
-                const uint32_t st = (uint32_t)((ch_start[c] >> (16 * cls)) & 0xFFFFull);
-                order[cls_base[cls] + st + (v >> 3)] = (uint16_t)q;
+                const unsigned long long cs = ch_start[c];
+                if (cls == 7) {
+                    // finished by the first evaluation: after the solve order, in slot order (every chunk before c is full)
+                    uint32_t todo_before = 0;
+#pragma unroll
+                    for (int k = 0; k < RTMI_RK_CLASSES; ++k)
+                        todo_before += (uint32_t)((cs >> (16 * k)) & 0xFFFFull);
+                    order[(uint32_t)n_todo + (uint32_t)(c * 64) - todo_before + (v >> 3)] = (uint16_t)q;
+                } else {
+                    const uint32_t st = (uint32_t)((cs >> (16 * cls)) & 0xFFFFull);
+                    order[cls_base[cls] + st + (v >> 3)] = (uint16_t)q;
+                }
             }
         }
         __syncthreads();
@@ -793,18 +806,43 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
-                if (s.conv)
-                    rk[slot] |= RTMI_RK_CONV;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // p before the flag the time pass polls
+                rk[slot] |= s.conv ? (RTMI_RK_DONE | RTMI_RK_CONV) : RTMI_RK_DONE;
             }
         }
-        __syncthreads();
+        // Rounds with express waves go on WITHOUT a barrier: the local waves, which leave the solve loop while the
+        // express waves still finish the longest sources, start on the travel times at once (below).
+        if (!split)
+            __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[2] = clock64();
 
-        // ---- c. travel times in sorted order ----------------------------------------------------
-        for (int q0 = wib * 64; q0 < nq; q0 += nwib * 64) {
-            const int q = q0 + lane;
-            const bool valid = q < nq;
+        // ---- c. travel times, in the order of the solve queue ------------------------------------------------
+        // order[] lists every record: the solve queue (longest first) and then the records finished by their first
+        // evaluation, each part in slot order, so a chunk of 64 still has one or two layer counts.  The chunks are
+        // dealt to the waves statically (the summation order of the fused logL is the same on every run); with
+        // express waves the local waves take them all, and a wave waits for a chunk whose sources are still being
+        // solved (flag RTMI_RK_DONE, set after p is stored).  The head of the queue was handed out first and is long
+        // finished, so nearly the whole pass runs in the shadow of the solve's tail.
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        volatile lds_u32 *rk_poll = (volatile lds_u32 *)rk;
+        const int tp_first = split ? wib - 4 : wib, tp_waves = split ? nwib - 4 : nwib;
+        for (int q0 = tp_first * 64; q0 < nq && !express; q0 += tp_waves * 64) {
+            const bool valid = q0 + lane < nq;
+            const int q = valid ? (int)order[q0 + lane] : 0;
+            if (split) {
+                int polls = 0;
+#pragma unroll 1
+                while (!__all(!valid || (rk_poll[q] & RTMI_RK_DONE) != 0u)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++polls > (1 << 22)) {  // never expected: flag it and go on with what is there
+                        if (a.d_status && lane == 0)
+                            atomicOr(a.d_status, 4);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
             const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
             const T p = valid ? rp[q] : T(0.0);
