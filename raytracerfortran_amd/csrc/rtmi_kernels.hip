@@ -820,47 +820,77 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         // ---- c. travel times, in the order of the solve queue ------------------------------------------------
         // order[] lists every record: the solve queue (longest first) and then the records finished by their first
         // evaluation, each part in slot order, so a chunk of 64 still has one or two layer counts.  The chunks are
-        // dealt to the waves statically (the summation order of the fused logL is the same on every run); with
-        // express waves the local waves take them all, and a wave waits for a chunk whose sources are still being
-        // solved (flag RTMI_RK_DONE, set after p is stored).  The head of the queue was handed out first and is long
-        // finished, so nearly the whole pass runs in the shadow of the solve's tail.
-        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-        volatile lds_u32 *rk_poll = (volatile lds_u32 *)rk;
-        const int tp_first = split ? wib - 4 : wib, tp_waves = split ? nwib - 4 : nwib;
-        for (int q0 = tp_first * 64; q0 < nq && !express; q0 += tp_waves * 64) {
-            const bool valid = q0 + lane < nq;
-            const int q = valid ? (int)order[q0 + lane] : 0;
-            if (split) {
-                int polls = 0;
+        // dealt to the waves statically.  With express waves, the local waves take all chunks but the last four and
+        // start as soon as they leave the solve loop; a chunk is taken when all its sources are finished (flag
+        // RTMI_RK_DONE, set after p is stored), otherwise the wave goes on to its next chunk and comes back -- the
+        // head of the queue was handed out first and is long finished, so nearly the whole pass runs in the shadow of
+        // the solve's tail.  The last four chunks (the last sources handed out) wait for the express waves, which
+        // finish last anyway.  Residuals of the fused logL are parked in LDS and added up afterwards in chunk order:
+        // the sum does not depend on which chunk happened to be ready first.
+        {
+            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+            volatile lds_u32 *rk_poll = (volatile lds_u32 *)rk;
+            const int C = (nq + 63) >> 6;
+            const int E = split ? (C < 4 ? C : 4) : 0;
+            const int c_first = express ? C - E + wib : (split ? wib - 4 : wib);
+            const int c_stride = split ? nwib - 4 : nwib;
+            const int c_end = express ? (wib < E ? c_first + 1 : c_first) : C - E;
+            const int nmine = c_end > c_first ? (c_end - c_first + c_stride - 1) / c_stride : 0;  // <= 11
+            uint32_t pending = nmine > 0 ? (nmine >= 32 ? 0xFFFFFFFFu : (1u << nmine) - 1u) : 0u;
+            int polls = 0;
 #pragma unroll 1
-                while (!__all(!valid || (rk_poll[q] & RTMI_RK_DONE) != 0u)) {
+            while (pending) {
+                bool progress = false;
+                uint32_t scan = pending;
+#pragma unroll 1
+                while (scan) {
+                    const int j = __builtin_ctz(scan);
+                    scan &= scan - 1u;
+                    const int q0 = (c_first + j * c_stride) * 64;
+                    const bool valid = q0 + lane < nq;
+                    const int q = valid ? (int)order[q0 + lane] : 0;
+                    if (split) {
+                        if (!__all(!valid || (rk_poll[q] & RTMI_RK_DONE) != 0u))
+                            continue;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    pending &= ~(1u << j);
+                    progress = true;
+                    const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+                    const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
+                    const T p = valid ? rp[q] : T(0.0);
+                    const T z = valid ? rz[q] : T(1.0);
+                    const int nfw = wave_max_i32(valid ? il : 0);
+                    T tt = travel_time(t, p, il, nfw, il, z, valid);
+                    if (!(key & RTMI_RK_CONV))
+                        tt = -T(999.0);
+                    if (valid) {
+                        const int loc = (int)(key & RTMI_RK_LOC_MASK);
+                        const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
+                        if (WANT_T)
+                            a.d_timeP[k] = tt;
+                        if (WANT_P)
+                            a.d_p_final[k] = p;
+                        if (WANT_SS) {
+                            const T r = a.d_obs[k] - tt;
+                            rR[q] = r * r;  // the record's R is not needed any more
+                        }
+                    }
+                }
+                if (!progress) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++polls > (1 << 22)) {  // never expected: flag it and go on with what is there
+                    if (++polls > (1 << 22)) {  // never expected: flag it and leave the rest unwritten
                         if (a.d_status && lane == 0)
                             atomicOr(a.d_status, 4);
                         break;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
-            const T p = valid ? rp[q] : T(0.0);
-            const T z = valid ? rz[q] : T(1.0);
-            const int nfw = wave_max_i32(valid ? il : 0);
-            T tt = travel_time(t, p, il, nfw, il, z, valid);
-            if (!(key & RTMI_RK_CONV))
-                tt = -T(999.0);
-            if (valid) {
-                const int loc = (int)(key & RTMI_RK_LOC_MASK);
-                const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
-                if (WANT_T)
-                    a.d_timeP[k] = tt;
-                if (WANT_P)
-                    a.d_p_final[k] = p;
-                if (WANT_SS) {
-                    const T r = a.d_obs[k] - tt;
-                    ss = ss + r * r;
+            if (WANT_SS) {
+                for (int j = 0; j < nmine; ++j) {
+                    const int q0 = (c_first + j * c_stride) * 64;
+                    if (q0 + lane < nq)
+                        ss = ss + rR[order[q0 + lane]];  // written by this very lane
                 }
             }
         }
