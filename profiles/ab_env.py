@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/ab_env.py VAR v0 v1 ... -- interleaved sweep of an experiment's environment knob (read by the launcher at
-every launch of an experimental build) on three shapes: C2 1e6, the tempering slot (32 x 1e4, k <= 10) and config 4's
+every launch of an experimental build; VAR = opt:<name> sweeps the scheduling knob rtmi_set_option(<name>) instead) on three shapes: C2 1e6, the tempering slot (32 x 1e4, k <= 10) and config 4's
 share (32 x 1e5, k <= 30).  Results are checked equal across the values."""
 import ctypes, os, sys
 import numpy as np
@@ -39,7 +39,10 @@ res = {(s, m): [] for s in shapes for m in vals}
 ref = {}
 for r in range(7):
     for m in vals:
-        os.environ[var] = m
+        if var.startswith("opt:"):
+            rt.set_option(var[4:], int(m))
+        else:
+            os.environ[var] = m
         for s, fn in shapes.items():
             o = fn(); torch.cuda.synchronize()
             if s not in ref:

@@ -825,8 +825,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
         // RTMI_RK_DONE, set after p is stored), otherwise the wave goes on to its next chunk and comes back -- the
         // head of the queue was handed out first and is long finished, so nearly the whole pass runs in the shadow of
         // the solve's tail.  The last four chunks (the last sources handed out) wait for the express waves, which
-        // finish last anyway.  Residuals of the fused logL are parked in LDS and added up afterwards in chunk order:
-        // the sum does not depend on which chunk happened to be ready first.
+        // finish last anyway.  Squared residuals of the fused logL are parked in LDS and added up after the pass.
         {
             typedef __attribute__((address_space(3))) uint32_t lds_u32;
             volatile lds_u32 *rk_poll = (volatile lds_u32 *)rk;
@@ -886,15 +885,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
                     }
                 }
             }
-            if (WANT_SS) {
-                for (int j = 0; j < nmine; ++j) {
-                    const int q0 = (c_first + j * c_stride) * 64;
-                    if (q0 + lane < nq)
-                        ss = ss + rR[order[q0 + lane]];  // written by this very lane
-                }
-            }
         }
         __syncthreads();
+        if (WANT_SS) {
+            // the squared residuals, added up in SLOT order by all waves: an order that depends on nothing but the
+            // sources and the launch geometry (not on the scheduling knobs, not on which chunk was ready first)
+            for (int q = wib * 64 + lane; q < nq; q += nwib * 64)
+                ss = ss + rR[q];
+            __syncthreads();  // before the next round reuses the record area
+        }
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[3] = clock64();
     }

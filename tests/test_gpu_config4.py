@@ -119,3 +119,34 @@ def test_config4_host_entry_points(rt, O):
         assert abs(L[m] - ll) <= 1e-11 * abs(ll), (m, L[m], ll)
         ss = float(np.sum((w["obs"] - ref[m]) ** 2))
         assert abs(SS[m] - ss) <= 1e-10 * ss
+
+
+def test_logl_does_not_depend_on_scheduling_knobs(rt):
+    """The fused logL adds squared residuals in an order fixed by the sources and the launch geometry alone: the
+    queue's knobs (refill threshold, hand-over rules, tail grouping) -- which decide which wave solves which source and
+    when a chunk of travel times can be written -- must not change a bit of it, nor may a repetition of the launch.
+    (waves_per_simd changes the geometry itself and is not covered.)  Shapes: a tempering slot (one round with and
+    without express waves) and the config-4 share."""
+    import torch
+    from raytracerfortran_amd import synthetic as S
+    defaults = {"refill_min": 32, "retire_max": 12, "promote_age": 3, "tail_group": 0}
+    for nm, n, kmax in ((32, 10_000, 10), (8, 100_000, 30)):
+        V, D, NL = S.prior_models(nm, 2, kmax, seed=5, ld=kmax + 1)
+        off, dep = S.sampler_sources(n, 6)
+        rng = np.random.default_rng(7)
+        a = [torch.tensor(x, device="cuda") for x in (V, D, NL, off, dep)]
+        obs, sd = torch.tensor(rng.uniform(0.5, 2.0, n), device="cuda"), torch.full((nm,), 0.02, dtype=torch.float64, device="cuda")
+        ref = None
+        try:
+            for knobs in ({}, {}, {"retire_max": 0, "promote_age": 0}, {"retire_max": 40, "promote_age": 1},
+                          {"refill_min": 8, "tail_group": 64}, {"refill_min": 64, "retire_max": 4, "promote_age": 6}):
+                for k, v in {**defaults, **knobs}.items():
+                    rt.set_option(k, v)
+                _, L = rt.trace_batch_device(*a, obs=obs, sd=sd, want_timeP=False)
+                L = L.cpu().numpy()
+                ref = L if ref is None else ref
+                assert np.array_equal(L, ref), knobs
+        finally:
+            for k, v in defaults.items():
+                rt.set_option(k, v)
+    assert rt.load_library().rtmi_device_status() == 0
