@@ -210,7 +210,7 @@ int rtmi_device_cus(void);
  *   "waves_per_simd"  resident waves per SIMD of the fused kernel, 1..8 (default 4)
  *   "refill_min"      idle lanes of a wave that trigger a refill, 1..64 (default 32)
  *   "tail_group"      end-game concentration: wave group g (4 waves each) stops taking new sources once
- *                     fewer than g x tail_group remain queued, 0..4096 (default 0 = off)
+ *                     fewer than g x tail_group remain queued, 0..4096 (default 128; 0 = off)
  *   "promote_age"     waves 4.. of a workgroup hand a source over to the express waves 0..3 (one per SIMD) once it
  *                     has taken this many evaluation trips, 0..64 (default 3, 0 = off; applies to rounds of at
  *                     least two records per lane)

@@ -19,7 +19,7 @@ def make(nm, n, kmax):
             torch.full((nm,), 0.02, dtype=torch.float64, device=dev)]
 for nm, n, kmax in ((32, 10000, 10), (32, 100000, 30), (256, 10000, 30)):
     tV, tD, tN, to, tz, obs, sd = make(nm, n, kmax)
-    settings = [dict(waves_per_simd=w, refill_min=m, tail_group=t) for w in (1, 2, 3, 4) for m in (8, 16) for t in (0, 512)]
+    settings = [dict(waves_per_simd=w, refill_min=m, tail_group=t) for w in (3, 4) for m in (16, 32) for t in (0, 128, 512)]
     res = {i: [] for i in range(len(settings))}
     for r in range(5):
         for i, st in enumerate(settings):

@@ -29,5 +29,5 @@ for N in [int(x) for x in sys.argv[1:]] or [1_000_000]:
     print("N =", N)
     for n, _ in settings:
         a = np.array(res[n]); print("  %-12s median %.4f ms  min %.4f ms" % (n, np.median(a), a.min()))
-    for k, x in dict(refill_min=32, retire_max=12, promote_age=3, tail_group=0, waves_per_simd=4).items():
+    for k, x in dict(refill_min=32, retire_max=12, promote_age=3, tail_group=128, waves_per_simd=4).items():
         rt.set_option(k, x)

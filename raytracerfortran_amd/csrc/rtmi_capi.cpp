@@ -89,7 +89,7 @@ static std::mutex g_tune_mu;
 static Tuning &tuning_locked()
 {
     static Tuning t = [] {
-        Tuning v{0, 4, 32, 0, 12, 3, nullptr, 1};
+        Tuning v{0, 4, 32, 128, 12, 3, nullptr, 1};
         if (const char *e = getenv("RTMI_FORCE_PATH")) {
             if (!strcmp(e, "plain"))
                 v.force_path = 1;

@@ -47,7 +47,7 @@ for it in range(iters):
         p = torch.empty(n, dtype=dt, device="cuda")
         t = rt.trace_device(*a, p_final=p).cpu().numpy()
     finally:
-        for kk, vv in dict(path=0, waves_per_simd=4, refill_min=32, tail_group=0, retire_max=12, promote_age=3).items():
+        for kk, vv in dict(path=0, waves_per_simd=4, refill_min=32, tail_group=128, retire_max=12, promote_age=3).items():
             rt.set_option(kk, vv)
     if f32:
         ref, pref, nl = O.oracle_dff_f32(v, d, off, dep, want_p=True)

@@ -129,7 +129,7 @@ def test_logl_does_not_depend_on_scheduling_knobs(rt):
     without express waves) and the config-4 share."""
     import torch
     from raytracerfortran_amd import synthetic as S
-    defaults = {"refill_min": 32, "retire_max": 12, "promote_age": 3, "tail_group": 0}
+    defaults = {"refill_min": 32, "retire_max": 12, "promote_age": 3, "tail_group": 128}
     for nm, n, kmax in ((32, 10_000, 10), (8, 100_000, 30)):
         V, D, NL = S.prior_models(nm, 2, kmax, seed=5, ld=kmax + 1)
         off, dep = S.sampler_sources(n, 6)
@@ -139,7 +139,7 @@ def test_logl_does_not_depend_on_scheduling_knobs(rt):
         ref = None
         try:
             for knobs in ({}, {}, {"retire_max": 0, "promote_age": 0}, {"retire_max": 40, "promote_age": 1},
-                          {"refill_min": 8, "tail_group": 64}, {"refill_min": 64, "retire_max": 4, "promote_age": 6}):
+                          {"refill_min": 8, "tail_group": 0}, {"refill_min": 64, "retire_max": 4, "promote_age": 6}):
                 for k, v in {**defaults, **knobs}.items():
                     rt.set_option(k, v)
                 _, L = rt.trace_batch_device(*a, obs=obs, sd=sd, want_timeP=False)

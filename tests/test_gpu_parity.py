@@ -229,7 +229,7 @@ def test_fused_kernel_equals_plain_kernel(rt, O, n, wps, refill, tail, retire, p
         rt.set_option("path", 0)
         rt.set_option("waves_per_simd", 4)
         rt.set_option("refill_min", 32)
-        rt.set_option("tail_group", 0)
+        rt.set_option("tail_group", 128)
         rt.set_option("retire_max", 12)
         rt.set_option("promote_age", 3)
     assert np.array_equal(t1, t2, equal_nan=True) and np.array_equal(t2, t3, equal_nan=True)
