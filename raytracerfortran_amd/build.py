@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "librtmi.so")
 LIB7 = os.path.join(HERE, "librtmi_dff7.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("rtmi_kernels.hip", "rtmi_capi.cpp", "rtmi_pt.hip", "rtmi_comm.cpp")]
 SHIM7 = os.path.join(CSRC, "rtmi_dff7_shim.c")
-HEADERS = [os.path.join(CSRC, h) for h in ("rtmi_kernels.h", "rtmi_device.hpp", "rtmi_host.h", "rtmi_pt_rules.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("rtmi_kernels.h", "rtmi_device.hpp", "rtmi_host.h", "rtmi_pt_rules.h", "rtmi_pt_dev.hpp")] + \
           [os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

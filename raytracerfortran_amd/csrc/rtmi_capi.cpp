@@ -231,6 +231,52 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
     return RTMI_OK;
 }
 
+// The tempering sampler's sweep as one persistent launch (rtmi_kernels.hip::pt_sweep_kernel): same arguments as the
+// batched likelihood launch of launch_batch plus the sampler's device view.  RTMI_ERR_UNSUPPORTED-like outcome (any
+// non-zero return WITHOUT a sticky error message) tells the caller to use the per-slot launches instead.
+int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
+                    int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                    const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
+                    const void *sweep_args, hipStream_t stream)
+{
+    const rtmi::PtSweepArgs *w = static_cast<const rtmi::PtSweepArgs *>(sweep_args);
+    const Tuning tn = tuning_snapshot();
+    if (!batch_takes_fused(tn, nsrc)) {
+        if (getenv("RTMI_PT_VERBOSE"))
+            fprintf(stderr, "rtmi: persistent sweep needs the fused kernel path\n");
+        return -1;
+    }
+    int *d_status = nullptr;
+    int rc = status_word_for(stream, &d_status);
+    if (rc)
+        return rc;
+    rtmi::FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.d_vels = d_vels;
+    fa.d_depths = d_depths;
+    fa.d_nlayers = d_nlayers;
+    fa.ld_model = ld_model;
+    fa.refill_min = tn.refill_min;
+    fa.tail_group = tn.tail_group;
+    fa.retire_max = tn.retire_max;
+    fa.d_status = d_status;
+    fa.promote_age = tn.promote_age;
+    fa.allow_skip = 1;
+    fa.d_src_offset = d_src_offset;
+    fa.d_src_depth = d_src_depth;
+    fa.nsrc = nsrc;
+    fa.d_obs = d_obs;
+    fa.d_partial = d_partial;
+    const hipError_t e = rtmi_launch_pt_sweep(&fa, ptdev, ptdev_bytes, w, nchains, max_nlayers, cus, tn.solve_waves, stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the caller falls back
+        if (getenv("RTMI_PT_VERBOSE"))
+            fprintf(stderr, "rtmi: persistent sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
+        return -1;
+    }
+    return RTMI_OK;
+}
+
 }  // namespace rtmi_host
 
 using namespace rtmi_host;

@@ -80,6 +80,13 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
                  hipStream_t stream);
 // workgroups per model (= partial sums per model) launch_batch will use for this shape
 int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus);
+// The tempering sampler's sweep as one persistent cooperative launch (rtmi_kernels.hip::pt_sweep_kernel): the batched
+// likelihood's arguments plus the sampler's device view (rtmi_pt_dev::PtDev, opaque here) and the sweep's
+// rtmi::PtSweepArgs.  Non-zero = not available for this shape / device state: use the per-slot launches.
+int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
+                    int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
+                    const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
+                    const void *sweep_args, hipStream_t stream);
 
 }  // namespace rtmi_host
 

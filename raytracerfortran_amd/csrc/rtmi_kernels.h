@@ -70,6 +70,20 @@ struct FusedArgsT {
 };
 typedef FusedArgsT<double> FusedArgs;
 
+// Arguments of the persistent sweep kernel of the tempering sampler (pt_sweep_kernel): every chain has gx workgroups,
+// which run the chain's proposal slots one after the other and meet only among themselves.
+struct PtSweepArgs {
+    int nslots_k;          // node slots of this sweep: 1 birth/death slot + 2 nslots_k - 1 perturbation slots + the sigma move
+    int gx;                // workgroups per chain
+    int nchains;
+    int xcd_map;           // 1: the workgroups of a chain are blockIdx values that land on one XCD (shared L2)
+    unsigned int epoch;    // slots the handle has run through this kernel before this launch (the words below only grow)
+    unsigned int *flag;    // [nchains] slots whose model row the chain's leading workgroup has published
+    unsigned int *count;   // [nchains] workgroup arrivals (gx per slot)
+    unsigned int *abort_;  // [1] set when a bounded wait ran out: every workgroup leaves at its next wait
+    int lds_ctl;           // set by the launcher: byte offset of the kernel's own control word in dynamic LDS
+};
+
 }  // namespace rtmi
 
 extern "C" {
@@ -82,6 +96,11 @@ hipError_t rtmi_launch_trace_f32(const rtmi::TraceArgsT<float> *args, int nmodel
                                  hipStream_t stream);
 hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_nlayers, int num_cus,
                              int waves_per_simd, int *grid_x_out, hipStream_t stream);
+// ptdev: DEVICE copy of the sampler's device view (rtmi_pt_dev::PtDev, ptdev_bytes = its size: checked).  Cooperative launch of
+// nchains x w->gx workgroups; hipErrorCooperativeLaunchTooLarge (or any other error) = use the per-slot launches.
+hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
+                                const rtmi::PtSweepArgs *w, int nchains, int max_nlayers, int num_cus,
+                                int waves_per_simd, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
                                           unsigned long long *d_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,

@@ -50,9 +50,12 @@
 //  fp32 path of BASELINE config 5 (its layer term has a guarded form of its own, everything else is IEEE).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "rtmi_device.hpp"
 #include "rtmi_kernels.h"
+#include "rtmi_pt_dev.hpp"
 
 namespace rtmi {
 
@@ -103,16 +106,16 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
 // (bit 8) and its outputs are filled with NaN -- loud, never silently wrong.
 template <typename T>
 __device__ __forceinline__ bool reject_model_row(int nlayers, int max_nlayers, int allow_skip, int *d_status,
-                                                 T *timeP_row, int64_t nsrc, T *partial_slot)
+                                                 T *timeP_row, int64_t nsrc, T *partial_slot, int bx, int gx)
 {
     if (nlayers >= 1 && nlayers <= max_nlayers)
         return false;
     const bool skip = allow_skip && nlayers == 0;
     if (!skip) {
-        if (threadIdx.x == 0 && blockIdx.x == 0 && d_status)
+        if (threadIdx.x == 0 && bx == 0 && d_status)
             atomicOr(d_status, 8);
         if (timeP_row)
-            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nsrc; k += (int64_t)gridDim.x * blockDim.x)
+            for (int64_t k = (int64_t)bx * blockDim.x + threadIdx.x; k < nsrc; k += (int64_t)gx * blockDim.x)
                 timeP_row[k] = T(__builtin_nan(""));
     }
     if (partial_slot && threadIdx.x == 0)
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
     const int nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
     if (a.d_nlayers && reject_model_row<T>(nlayers, a.max_nlayers, a.allow_skip, a.d_status,
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
-                                           WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr))
+                                           WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr,
+                                           (int)blockIdx.x, (int)gridDim.x))
         return;
     const LayerTable<T> t = carve_table(lds, nlayers, false, a.skiptab != 0);
     stage_model(t, a.d_vels + (int64_t)m * a.ld_model, a.d_depths + (int64_t)m * a.ld_model, nlayers);
@@ -218,16 +222,15 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // workgroup row b of a model owns chunks b, b + gridDim.x, ... of the sources.
 // ROWS: the launch's layer tables carry one row per stack height (models of up to RTMI_ROWS_MAX_NL interfaces); a
 // template parameter so that each instantiation holds one form of the evaluation loop only (code size).
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false>
-__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
+// The body is a device function of (model m, workgroup row bx of gx rows): the kernel below calls it with the launch's
+// grid indices, the persistent sweep kernel of the tempering sampler (pt_sweep_kernel) once per proposal slot.
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, bool ROWS>
+__device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const int bx, const int gx, T *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
-    T *lds = reinterpret_cast<T *>(lds_raw);
-    const int m = blockIdx.y;
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
     if (a.d_nlayers && reject_model_row<T>(a.nlayers, a.max_nlayers, a.allow_skip, a.d_status,
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
-                                           WANT_SS ? a.d_partial + ((int64_t)m * gridDim.x + blockIdx.x) : nullptr))
+                                           WANT_SS ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx))
         return;
     a.d_vels += (int64_t)m * a.ld_model;
     a.d_depths += (int64_t)m * a.ld_model;
@@ -242,12 +245,12 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     // layer table is built.
     const int64_t nchunks_all = (a.nsrc + 63) / 64;
     auto depth_of = [&](int64_t j0, int c) {
-        const int64_t chunk = (int64_t)blockIdx.x + (j0 + c) * (int64_t)gridDim.x;
+        const int64_t chunk = (int64_t)bx + (j0 + c) * (int64_t)gx;
         const int64_t k = chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_depth[k] : T(0.0);
     };
     auto offset_of = [&](int64_t j0, int c) {
-        const int64_t chunk = (int64_t)blockIdx.x + (j0 + c) * (int64_t)gridDim.x;
+        const int64_t chunk = (int64_t)bx + (j0 + c) * (int64_t)gx;
         const int64_t k = chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
@@ -283,15 +286,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
     unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [128]
     unsigned long long *ch_start = ch_cnt + 128;                                  // [128]
 
-    const int64_t b = blockIdx.x;
-    const int64_t nblocks = gridDim.x;
+    const int64_t b = bx;
+    const int64_t nblocks = gx;
     const int64_t nchunks = (a.nsrc + 63) / 64;
     const int CH = slots / 64;
     const int nl_max = a.nlayers + 1;
 
     // Diagnostic phase clocks (NULL in normal runs): per workgroup {start, after sort, after solve, after time}
     // of its FIRST round, in shader-clock ticks.  The stamps go to a buffer nothing else reads.
-    unsigned long long *stamps = (DIAG && a.d_stamps) ? a.d_stamps + RTMI_STAMPS_PER_WG * blockIdx.x : nullptr;
+    unsigned long long *stamps = (DIAG && a.d_stamps) ? a.d_stamps + RTMI_STAMPS_PER_WG * bx : nullptr;
     const bool fine = DIAG && stamps && a.diag_fine;  // per-trip clocks and counters (they slow the loop down by a quarter)
     for (int64_t j0 = 0; b + j0 * nblocks < nchunks; j0 += CH) {
         // ---- a. load + workgroup-local STABLE counting sort ------------------------------------
@@ -911,9 +914,140 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
             T tot = wsum[0];
             for (int w = 1; w < nwib; ++w)
                 tot = tot + wsum[w];
-            a.d_partial[(int64_t)m * gridDim.x + blockIdx.x] = tot;
+            a.d_partial[(int64_t)m * gx + bx] = tot;
         }
     }
+}
+
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
+    fused_body<T, WANT_P, WANT_T, WANT_SS, DIAG, ROWS>(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x,
+                                                       reinterpret_cast<T *>(lds_raw));
+}
+
+// ---- the tempering sampler's sweep as ONE persistent launch ---------------------------------------------------------
+// What a sweep is (rtmi_pt.hip): per proposal slot, the step of every chain (decide the previous proposal, draw the
+// next one, write it as a model row) and then the likelihood of every proposed model over the shared sources.  As
+// separate launches (two per slot) every chain waits at every slot for the slowest workgroup of ALL chains, and the
+// launch boundaries themselves are a tenth of the sweep.  Here every chain owns gx workgroups for the whole sweep:
+//   leading workgroup (row 0):  step of slot s  ->  publish (flag[chain] = epoch + s + 1)
+//   all gx workgroups:          wait for the flag, evaluate their share of the sources (fused_body), add their residual
+//                               sum to partial[chain][row], arrive (count[chain] += 1)
+//   leading workgroup:          wait for gx arrivals, go on to slot s + 1
+// so a chain whose sources happen to finish early -- or whose proposal fell outside the prior: no evaluation at all --
+// runs ahead of the others; the chains meet again at the end of the kernel (the temperature exchange needs them all).
+// Results are those of the per-slot launches bit for bit: same step function (pt_step_group), same likelihood body,
+// same order of the residual sums.
+// The workgroups must all be resident (they wait for each other): the launch is cooperative, and every wait is bounded --
+// a wait that runs out sets the abort word and bit 16 of the fault word, and every workgroup leaves.
+// Memory: what one workgroup writes for another (model row, NL, partial sums) is written, fenced at device scope
+// (__threadfence) by its writers, and only then announced through an atomic; the reader takes the atomic with acquire
+// semantics at device scope and invalidates the scalar cache before it reads.
+__device__ __forceinline__ bool pt_wait_reached(volatile unsigned int *word, unsigned int target, volatile unsigned int *abort_word,
+                                                int *d_status)
+{
+    int polls = 0;
+#pragma unroll 1
+    for (;;) {
+        // relaxed polls (an acquire per poll would invalidate the caches under the workgroups that are computing), one
+        // acquire fence once the word is there
+        const unsigned int v = __hip_atomic_load((unsigned int *)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // hipcc: agent scope
+            return true;
+        }
+        if (__hip_atomic_load((unsigned int *)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            return false;
+        __builtin_amdgcn_s_sleep(16);  // 2 ... 16 measured alike
+        if (++polls > (1 << 23)) {  // seconds: never expected
+            __hip_atomic_store((unsigned int *)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d_status)
+                atomicOr(d_status, 16);
+            return false;
+        }
+    }
+}
+
+// The step is a real call (its own registers; the handle's device view is read from memory inside it): inlined next to
+// the likelihood body it drove that body into scratch.
+__device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chain, int decide, int sigma, int propose,
+                                          int ivo, int ipar)
+{
+    const rtmi_pt_dev::PtDev d = *dp;
+    if (d.K <= 16) {
+        if (threadIdx.x < 16)
+            rtmi_pt_dev::pt_step_group<16>(d, chain, decide, sigma, propose, ivo, ipar);
+    } else if (d.K <= 32) {
+        if (threadIdx.x < 32)
+            rtmi_pt_dev::pt_step_group<32>(d, chain, decide, sigma, propose, ivo, ipar);
+    } else if (threadIdx.x < 64) {
+        rtmi_pt_dev::pt_step_group<64>(d, chain, decide, sigma, propose, ivo, ipar);
+    }
+}
+
+template <bool ROWS>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, PtSweepArgs w)
+{
+    using namespace rtmi_pt_dev;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    int *const d_status = a.d_status;
+    volatile int &go_on = *reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_raw) + w.lds_ctl);  // past the likelihood's LDS
+    const int gx = w.gx;
+    int chain, row;
+    if (w.xcd_map) {
+        // consecutive blockIdx values go to consecutive XCDs: give a chain gx workgroups of ONE XCD, so that what they
+        // pass to each other stays in that XCD's L2
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        chain = xcd * (w.nchains >> 3) + loc / gx;
+        row = loc % gx;
+    } else {
+        chain = blockIdx.x / gx;
+        row = blockIdx.x % gx;
+    }
+    const int S = 2 * w.nslots_k;  // slots with an evaluation: birth/death, then (node 0, v), (node 1, z), (node 1, v), ...
+    volatile unsigned int *flag = w.flag + chain, *count = w.count + chain, *abort_word = w.abort_;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const int decide = s == 0 ? (int)PT_NONE : (s == 1 ? (int)PT_BD : (int)PT_MH);
+        const int propose = s == 0 ? (int)PT_BD : (int)PT_MH;
+        const unsigned int target = w.epoch + (unsigned int)s + 1u;
+        if (row == 0) {
+            if (threadIdx.x < 64) {
+                pt_step_call(dp, chain, decide, 0, propose, s >> 1, s & 1);
+                __threadfence();  // the row is out before the flag; and this workgroup (one L1) reads it afresh, too
+            }
+            __builtin_amdgcn_s_dcache_inv();
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store((unsigned int *)flag, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0)
+                go_on = pt_wait_reached(flag, target, abort_word, d_status) ? 1 : 0;
+            __syncthreads();
+            if (!go_on)
+                return;
+            __builtin_amdgcn_s_dcache_inv();
+        }
+        fused_body<double, false, false, true, false, ROWS>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
+        __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
+        if (threadIdx.x == 0) {
+            __threadfence();
+            __hip_atomic_fetch_add((unsigned int *)count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (row == 0)
+                go_on = pt_wait_reached(count, target * (unsigned int)gx, abort_word, d_status) ? 1 : 0;
+        }
+        if (row == 0) {
+            __syncthreads();
+            if (!go_on)
+                return;
+            __builtin_amdgcn_s_dcache_inv();
+        }
+    }
+    // the last decision and the sigma move (EXPLORE_MH :521-575)
+    if (row == 0 && threadIdx.x < 64)
+        pt_step_call(dp, chain, (int)PT_MH, 1, (int)PT_NONE, 0, 0);
 }
 
 // Diagnostic: bitwise comparison of the guarded sqrt/divide with the plain operators.
@@ -1245,6 +1379,59 @@ extern "C" hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels
                                         int waves_per_simd, int *grid_x_out, hipStream_t stream)
 {
     return launch_fused_t<double>(*args, nmodels, max_nlayers, num_cus, waves_per_simd, grid_x_out, stream);
+}
+
+extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
+                                           const rtmi::PtSweepArgs *w, int nchains, int max_nlayers, int num_cus,
+                                           int waves_per_simd, hipStream_t stream)
+{
+    using namespace rtmi;
+    using rtmi_pt_dev::PtDev;
+    if (!args || !ptdev || !w || ptdev_bytes != sizeof(PtDev) || !args->d_obs || !args->d_nlayers || args->d_timeP)  // ptdev_bytes: layout check
+        return hipErrorInvalidValue;
+    {
+        const hipError_t e = prepare_fused_t<double>();
+        if (e != hipSuccess)
+            return e;
+    }
+    FusedArgs a = *args;
+    const PtDev *dp = static_cast<const PtDev *>(ptdev);  // a DEVICE copy of the handle's view
+    PtSweepArgs ws = *w;
+    a.max_nlayers = max_nlayers;
+    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
+    a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
+    size_t lds_bytes = 0;
+    int threads = 0;
+    const int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
+                                       &a.slots, &lds_bytes);
+    const bool verbose = getenv("RTMI_PT_VERBOSE") != nullptr;
+    ws.lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
+    lds_bytes = (size_t)ws.lds_ctl + 16;
+    if (gx != ws.gx || lds_bytes > 160 * 1024 || threads < 64 || ws.nchains != nchains) {
+        if (verbose)
+            fprintf(stderr, "rtmi_launch_pt_sweep: geometry gx %d (sweep %d), lds %zu, threads %d\n", gx, ws.gx, lds_bytes, threads);
+        return hipErrorInvalidValue;
+    }
+    // one round per evaluation only: a chain's share of the sources must fit the workgroup's LDS (it does for every
+    // shape the per-slot launches run in one round; otherwise leave it to them)
+    ws.xcd_map = (nchains % 8 == 0) ? 1 : 0;  // measured: 1.18 ms per sweep against 1.21 with a chain spread over the XCDs
+    const void *fn = a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true>)
+                            : reinterpret_cast<const void *>(&pt_sweep_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)
+        return e;
+    void *kargs[3] = {&a, &dp, &ws};
+    e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(gx * nchains)), dim3((unsigned)threads), kargs, lds_bytes, stream);
+    if (e != hipSuccess && verbose) {
+        int per_cu = -1, coop = -1, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);
+        fprintf(stderr, "rtmi_launch_pt_sweep: cooperative launch of %d x %d threads, %zu B LDS failed (%s); device cooperative %d, "
+                        "workgroups per CU %d\n", gx * nchains, threads, lds_bytes, hipGetErrorString(e), coop, per_cu);
+    }
+    return e;
 }
 
 extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers,

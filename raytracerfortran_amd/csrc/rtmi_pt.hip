@@ -29,37 +29,14 @@
 #include <vector>
 
 #include "rtmi_host.h"
+#include "rtmi_pt_dev.hpp"
 #include "rtmi_pt_rules.h"
 
 using namespace rtmi_host;
+using namespace rtmi_pt_dev;
 namespace R = rtmi_pt_rules;
 
 namespace {
-
-enum : int { PT_NONE = -1, PT_BD = 0, PT_MH = 1, PT_EVAL = 2 };
-
-// Everything the kernels need; passed by value.  Pointers are device pointers owned by the handle.
-struct PtDev {
-    int nchains, K, ld_model, gx;
-    int64_t ndata;
-    rtmi_pt_prior pr;
-    uint64_t seed;
-    uint32_t stream_id;
-    const double *logpk;  // [kmax + 2] Poisson prior, log
-    // chain state
-    int *k;
-    double *z, *v;        // [nchains][K]
-    double *sd, *logL, *ss, *beta;
-    unsigned long long *ctr;
-    // proposal of the current slot
-    int *pk, *pactive;    // pactive: 0 none, 1 proposal awaiting its decision, 2 evaluation of the current state
-    double *pz, *pv, *plp;
-    // batch rows of the likelihood launch and its per-workgroup residual sums
-    double *V, *D;        // [nchains][ld_model]
-    int32_t *NL;          // 0 = inactive row
-    const double *partial;  // [nchains][gx]
-    long long *stats;     // [nchains][8]: acc/prop birth-death, acc/prop perturbation, acc/prop sigma, models evaluated, -
-};
 
 __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k)
 {
@@ -70,225 +47,16 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
 // Working arrays of pt_pack_current_kernel (one thread per chain) live in LDS, not in private (scratch) memory: the
 // rules index them dynamically.  Layout: thread t owns [t * stride, (t + 1) * stride).
 #define PT_BLOCK 64
-#define PT_STEP_THREADS 256
 
-// pt_step_kernel: [decide the previous slot] [sigma move] [propose the next slot], one GROUP of G lanes per chain
-// (G = 16, 32 or 64 >= K, groups never straddle a wave).  Lane i of a group holds node i of its chain in registers;
-// everything scalar (the residual sum, the likelihood, the random draws, the acceptance tests) is computed by all G
-// lanes alike -- in SIMD that costs what one lane costs and needs no broadcast -- and everything per node (the bound
-// checks, the depth order, packing the model row, committing an accepted proposal) is one step wide instead of a loop
-// of dependent LDS round trips: the depth order is a rank count over lane shuffles (stable: ties keep node order,
-// as the insertion sort of rtmi_pt_rules.h::sorted_order), CHECKBOUNDS' spacing test reads the predecessor in depth
-// from the lane that holds rank - 1.  A one-thread-per-chain version of the same rules spent 60 % of its 12 us in the
-// sort and the packing loops (profiles/r02k/pt_step_phases.txt).  The rules and the random streams are unchanged:
-// chains advance bit for bit as before (tests/test_tempering.py compares with the host rules).
+// pt_step_kernel: the sampler's step (rtmi_pt_dev.hpp::pt_step_group) for every chain, one group of G lanes per chain.
 template <int G>
 __global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_kernel(PtDev d, int decide, int sigma, int propose, int ivo, int ipar)
 {
     constexpr int CPB = PT_STEP_THREADS / G;  // chains per block
-    const int i = threadIdx.x % G;            // the node this lane holds
     const int c = blockIdx.x * CPB + threadIdx.x / G;
     if (c >= d.nchains)
         return;  // whole groups leave together; there is no block-level barrier below
-    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
-    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gbase;
-    const int K = d.K;
-    const rtmi_pt_prior &p = d.pr;
-    const bool lead = i == 0;
-    const size_t row = (size_t)c * K + (i < K ? i : 0);
-    // ---- one round trip to HBM: this lane's node (current and proposed), the chain's scalars, the Poisson table ----
-    double zi = d.z[row], vi = d.v[row];
-    const double pzi = d.pz[row], pvi = d.pv[row];
-    const double lpk_lo = d.logpk[i < K + 2 ? i : K + 1], lpk_hi = d.logpk[i + G < K + 2 ? i + G : K + 1];
-    int k = d.k[c];
-    const int act = d.pactive[c];
-    const int pk = d.pk[c];
-    const unsigned long long ctr0 = d.ctr[c];
-    double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
-    const double beta = d.beta[c], plp = d.plp[c];
-    double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
-    if (decide != PT_NONE && act != 0)
-        for (int j = 0; j < d.gx; ++j)
-            part = part + d.partial[(size_t)c * d.gx + j];
-    long long *st = d.stats + (size_t)c * 8;
-    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
-
-    // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
-    if (decide != PT_NONE && act != 0) {
-        const double logl_new = R::gaussian_loglike(part, d.ndata, sd);
-        if (act == 2) {
-            ss = part;
-            logL = logl_new;
-        } else {
-            double lr = plp + (logl_new - logL) * beta;
-            if (lr > 50.0)
-                lr = 50.0;
-            if (lead)
-                st[2 * decide + 1] += 1;
-            if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
-                k = pk;
-                ss = part;
-                logL = logl_new;
-                if (lead) {
-                    st[2 * decide] += 1;
-                    d.k[c] = k;
-                }
-                if (i < k) {  // the proposal becomes the state
-                    zi = pzi;
-                    vi = pvi;
-                    d.z[row] = zi;
-                    d.v[row] = vi;
-                }
-            }
-        }
-        if (lead)
-            d.pactive[c] = 0;
-    }
-
-    // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
-    if (sigma) {
-        if (R::philox_uniform(rng) >= 0.10) {
-            const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
-            const double sd_new = sd + step * R::philox_normal(rng);
-            if (lead)
-                st[5] += 1;
-            if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
-                const double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
-                double lr = (logl_new - logL) * beta;
-                if (lr > 50.0)
-                    lr = 50.0;
-                if (!(R::philox_uniform(rng) >= exp(lr))) {
-                    sd = sd_new;
-                    logL = logl_new;
-                    if (lead)
-                        st[4] += 1;
-                }
-            }
-        }
-    }
-    if (lead) {
-        d.sd[c] = sd;
-        d.logL[c] = logL;
-        d.ss[c] = ss;
-    }
-    if (propose == PT_NONE) {
-        if (lead)
-            d.ctr[c] = rng.index;
-        return;  // launch-uniform
-    }
-
-    // ---- proposal of the next slot --------------------------------------------------------------------------------
-    // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the chain-dependent branches.
-    const int up = lane + 1 < 64 ? lane + 1 : 63;
-    const double z_up = __shfl(zi, up, 64), v_up = __shfl(vi, up, 64);  // node i + 1 (death shifts the nodes down)
-    const int kc = k < 1 ? 1 : k;
-    const double lpk_k = kc < G ? __shfl(lpk_lo, gbase + (kc & (G - 1)), 64) : __shfl(lpk_hi, gbase + ((kc - G) & (G - 1)), 64);
-    const double lpk_kp = kc + 1 < G ? __shfl(lpk_lo, gbase + ((kc + 1) & (G - 1)), 64)
-                                     : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
-    const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
-                                     : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
-    int qk = k;
-    double lp = 0.0;
-    bool have = false;
-    if (propose == PT_BD) {
-        // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
-        if (p.kmin != p.kmax) {
-            const double u = R::philox_uniform(rng);
-            int move;
-            if (k == p.kmax)
-                move = (u <= 0.3333) ? 2 : 0;
-            else if (k == p.kmin)
-                move = (u <= 0.3333) ? 1 : 0;
-            else
-                move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
-            if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
-                const double zn = (p.hmx - p.hmin) * R::philox_uniform(rng);
-                const double vn = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
-                if (i == k) {
-                    zi = zn;
-                    vi = vn;
-                }
-                qk = k + 1;
-                lp = lpk_kp - lpk_k;
-                have = true;
-            } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
-                int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
-                if (idel > k - 1)
-                    idel = k - 1;
-                if (i >= idel && i + 1 < k) {
-                    zi = z_up;
-                    vi = v_up;
-                }
-                qk = k - 1;
-                lp = lpk_km - lpk_k;
-                have = true;
-            }
-        }
-    } else if (ivo < k) {
-        // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
-        const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
-        const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
-        if (i == ivo) {
-            if (ipar == 0)
-                zi += step;
-            else
-                vi += step;
-        }
-        have = true;
-    }
-    // CHECKBOUNDS (prjmh_temper_rf.f90:1639-1679; rtmi_pt_rules.h::inside_bounds) over the qk proposed nodes
-    const bool in = have && i < qk;
-    bool bad = in && (vi < p.vmin || vi > p.vmax);
-    bad = bad || (in && qk > 1 && i >= 1 && (zi < 0.0 || zi > p.hmx));
-    int r = 0;  // rank of this node in depth (stable)
-    for (int j = 0; j < K; ++j) {
-        const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
-        r += (in && j < qk && (zj < zi || (zj == zi && j < i))) ? 1 : 0;
-    }
-    double prev = 0.0;  // the node above in depth; the rule measures the second node's spacing from 0
-    for (int j = 0; j < K; ++j) {
-        const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
-        const int rj = __shfl(r, gbase + (j & (G - 1)), 64);
-        if (j < qk && r >= 2 && rj == r - 1)
-            prev = zj;
-    }
-    bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
-    const bool ok = have && (__ballot(bad) & gmask) == 0ull;
-    int nl = 0;
-    if (ok) {
-        // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision
-        double *Vr = d.V + (size_t)c * d.ld_model, *Dr = d.D + (size_t)c * d.ld_model;
-        if (qk == 1) {
-            if (lead) {
-                Vr[0] = Vr[1] = vi;
-                Dr[0] = 9999.9;
-            }
-            nl = 1;
-        } else {
-            if (in) {
-                Vr[r] = vi;
-                if (r >= 1)
-                    Dr[r - 1] = zi;
-            }
-            nl = qk - 1;
-        }
-        if (in) {
-            d.pz[row] = zi;
-            d.pv[row] = vi;
-        }
-        if (lead) {
-            d.pk[c] = qk;
-            d.plp[c] = lp;
-            d.pactive[c] = 1;
-            st[6] += 1;  // a model that goes through the likelihood
-        }
-    } else if (have && lead) {
-        st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)
-    }
-    if (lead) {
-        d.NL[c] = nl;
-        d.ctr[c] = rng.index;
-    }
+    pt_step_group<G>(d, c, decide, sigma, propose, ivo, ipar);
 }
 
 // The current state of every chain as batch rows (rtmi_pt_evaluate).
@@ -409,6 +177,12 @@ struct rtmi_pt {
     // captured sweeps, by number of node slots
     std::map<int, hipGraphExec_t> graphs;
     bool use_graph = true;
+    // the sweep as one persistent cooperative launch (pt_sweep_kernel); falls back to the per-slot launches for good
+    // the first time the launch is refused (workgroups not co-resident, LDS, the plain-kernel path selected)
+    bool use_persistent = true;
+    unsigned int *d_sync = nullptr;  // flag[nchains] | count[nchains] | abort
+    PtDev *d_ptdev = nullptr;        // device copy of `d` (the persistent kernel's step reads it from memory)
+    unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
     int64_t launches = 0, models = 0;
 };
@@ -479,6 +253,25 @@ int sweep_once(rtmi_pt *h)
     if (ks > kmax)
         ks = kmax;
     h->kbound = ks;
+    if (h->use_persistent && h->d_sync && h->d_ptdev) {
+        rtmi::PtSweepArgs w;
+        memset(&w, 0, sizeof w);
+        w.nslots_k = ks;
+        w.gx = h->d.gx;
+        w.nchains = h->nchains;
+        w.epoch = h->epoch;
+        w.flag = h->d_sync;
+        w.count = h->d_sync + h->nchains;
+        w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
+        const size_t n = (size_t)h->nsrc;
+        if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
+                            h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream) == RTMI_OK) {
+            h->epoch += 2u * (unsigned int)ks;
+            h->launches += 1;
+            return RTMI_OK;
+        }
+        h->use_persistent = false;
+    }
     h->launches += 2 * ks;
     if (!h->use_graph)
         return enqueue_sweep(h, ks);
@@ -583,6 +376,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     h->nsrc = c.set_n;
     if (const char *e = getenv("RTMI_PT_GRAPH"))
         h->use_graph = strcmp(e, "0") != 0;
+    if (const char *e = getenv("RTMI_PT_PERSISTENT"))
+        h->use_persistent = strcmp(e, "0") != 0;
     const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n;
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
     const size_t nf64 = 4 * nc * K + 5 * nc + 2 * nc * ldm;
@@ -593,7 +388,10 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_i32, ni32 * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_u64, 9 * nc * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&h->d_partial, nc * (size_t)gx * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&h->d_logpk, ((size_t)prior->kmax + 2) * sizeof(double)) == hipSuccess;
+              hipMalloc((void **)&h->d_logpk, ((size_t)prior->kmax + 2) * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess;
+    if (ok)
+        ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess;
     if (ok) {
         // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
         ok = hipMemcpyAsync(h->d_set, c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) == hipSuccess &&
@@ -651,6 +449,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
              hipMemcpyAsync(d.sd, sd0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipMemcpyAsync(d.beta, b0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipMemcpyAsync(d.k, k0.data(), nc * sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipMalloc((void **)&h->d_ptdev, sizeof(PtDev)) == hipSuccess &&
+             hipMemcpyAsync(h->d_ptdev, &d, sizeof(PtDev), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipStreamSynchronize(h->stream) == hipSuccess;
     }
     if (!ok) {
@@ -672,7 +472,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
     for (auto &g : h->graphs)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
-                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val};
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);

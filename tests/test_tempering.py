@@ -461,3 +461,49 @@ def test_device_sweep_config4_miniature_k_up_to_30():
         assert abs(a["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref)), (i, k)
     lev, acc, prop = nat.get_ladder()
     assert sorted(lev.tolist()) == list(range(n)) and prop == 40 * 8 - 20   # 8 pairs on even rounds, 7 on odd ones
+
+
+@pytest.mark.gpu
+def test_persistent_sweep_equals_the_per_slot_launches():
+    """The two engines of the device-resident sweep -- two launches per proposal slot (replayed as a hipGraph) and ONE
+    persistent cooperative launch per sweep whose workgroups meet chain by chain (csrc/rtmi_kernels.hip::pt_sweep_kernel)
+    -- run the same step function and the same likelihood body: every chain, its statistics and the ladder must be
+    bit-identical after sweeps with exchanges.  The launch counter tells which engine ran."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod, synthetic as S
+    n, nch = 10_000, 32
+    off, dep = S.sampler_sources(n, 6)
+    rt.load_library(); rt.init(0)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"] + np.random.default_rng(3).normal(0, 0.016, n)
+    rt.set_sources(off, dep, obs)
+    nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    out = {}
+    old = os.environ.get("RTMI_PT_PERSISTENT")
+    try:
+        for engine in ("0", "1"):
+            os.environ["RTMI_PT_PERSISTENT"] = engine
+            h = raymod.NativeChains(nch, 11, n, T.Prior(), seed=21)
+            for i in range(nch):
+                h.set_chain(i, nodes, 0.016, 1.0)
+            h.evaluate()
+            h.set_ladder(nch, 0, np.arange(nch) // 2, 1.15 ** -np.arange(16.0))
+            h.run(25, 1, None, 0)
+            out[engine] = (h.get_all(), h.stats(), h.get_ladder()[0])
+            del h
+    finally:
+        if old is None:
+            os.environ.pop("RTMI_PT_PERSISTENT", None)
+        else:
+            os.environ["RTMI_PT_PERSISTENT"] = old
+    (a0, s0, l0), (a1, s1, l1) = out["0"], out["1"]
+    if s1["launches"] >= s0["launches"]:
+        pytest.skip("the cooperative launch was refused on this device: the per-slot launches ran twice")
+    assert s1["launches"] - 1 == 25                               # evaluate + one launch per sweep
+    for key in ("k", "sd", "logL", "ss", "beta"):
+        assert np.array_equal(a0[key], a1[key]), key
+    live = np.arange(a0["z"].shape[1])[None, :] < a0["k"][:, None]
+    assert np.array_equal(a0["z"][live], a1["z"][live]) and np.array_equal(a0["v"][live], a1["v"][live])
+    assert np.array_equal(l0, l1)
+    assert {k: v for k, v in s0.items() if k != "launches"} == {k: v for k, v in s1.items() if k != "launches"}
+    assert s0["acc_mh"] > 0 and s0["models"] > 25 * nch
+    assert rt.load_library().rtmi_device_status() == 0
