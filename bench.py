@@ -370,7 +370,9 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                                       "swap round every sweep (BASELINE configs 3/4 shape)" % nsrc,
                           "chains": nloc * world, "models_evaluated": models,
                           "launches_per_step": launches / max(1, args.steps),
-                          "engine": "device-resident sweep (rtmi_pt_run), swap exchange: "
+                          "engine": "device-resident sweep (rtmi_pt_run), "
+                                    + ("one persistent cooperative launch per sweep" if launches <= 2 * max(1, args.steps)
+                                       else "two launches per proposal slot, replayed as a hipGraph") + ", swap exchange: "
                                     + ("RCCL all-gather" if s.comm is not None else ("local" if world == 1 else "host gather (gloo rehearsal)")),
                           "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"])}}
         print(json.dumps(res), flush=True)

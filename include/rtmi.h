@@ -98,9 +98,14 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
  * The Metropolis-Hastings sweep of the reversible-jump tempering sampler, RESIDENT ON THE GPU (csrc/rtmi_pt.hip).
  * One handle = the tempered chains of one process (one GPU).  Chain state -- k nodes (depth, Vp), node 1 the surface
  * node whose depth is not perturbed, sigma, logL, SS, beta, the position of the chain's counter-based random stream --
- * lives in HBM; every proposal slot of a sweep (birth/death, then each (node, parameter) perturbation) is one small
- * kernel (decide the previous slot, propose the next) plus ONE batched likelihood launch for all chains over the
- * handle's source set; nothing of a sweep runs on the host and a sweep is replayed as a captured hipGraph:
+ * lives in HBM; every proposal slot of a sweep (birth/death, then each (node, parameter) perturbation) is a step
+ * (decide the previous slot, propose the next) plus the likelihood of every chain's proposal over the handle's source
+ * set; nothing of a sweep runs on the host.  A sweep is either ONE persistent cooperative launch in which the workgroups
+ * of a chain meet among themselves slot by slot, so chains run ahead of each other (needs the fused kernel path and all
+ * workgroups resident), or two launches per slot replayed as a captured hipGraph (RTMI_PT_GRAPH=0: launched one by one).
+ * The engines give bit-identical chains; the first rtmi_pt_run of >= 8 sweeps times two sweeps of each (one event
+ * synchronisation, once per handle) and keeps the persistent launch unless it is slower -- it is, several times, when
+ * other processes share the GPU.  RTMI_PT_PERSISTENT=0 / 1 decides up front instead.
  *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
  *   EXPLORE_MH           prjmh_temper_rf.f90:521-634   PROPOSAL_SDRT :1616   CHECKBOUNDS :1639
  *   TEMPSWP_MH           prjmh_temper_rf.f90:1329-1357 (replaces the pairing through rank 0, :331-349)
@@ -194,7 +199,8 @@ int rtmi_version(void);
 /*
  * Sticky fault word of the device code: 0, or a bit mask: bits 1, 2, 4 = a kernel ran out of one of its bounded waits
  * (the hand-over ring of the fused kernel is deadlock-free by construction; the bounds exist so that a fault could never
- * hang the GPU); bit 8 = a row of rtmi_trace_batch_device had d_nlayers outside [1, ld_model - 1].  The host-pointer
+ * hang the GPU; bit 16: a wait between the workgroups of the persistent sweep kernel -- the sweep was abandoned, the
+ * handle's chains are not to be trusted); bit 8 = a row of rtmi_trace_batch_device had d_nlayers outside [1, ld_model - 1].  The host-pointer
  * entry points check it after their synchronise and fail; callers of the asynchronous device entry points can poll it
  * after their own synchronise.  The word is allocated by rtmi_init or by the first un-captured call of any entry
  * point; a FIRST call made inside a stream capture is refused with RTMI_ERR_BAD_ARG (call rtmi_init before capturing).

@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -180,6 +181,10 @@ struct rtmi_pt {
     // the sweep as one persistent cooperative launch (pt_sweep_kernel); falls back to the per-slot launches for good
     // the first time the launch is refused (workgroups not co-resident, LDS, the plain-kernel path selected)
     bool use_persistent = true;
+    // which engine runs the sweeps: -1 = not decided yet (the first rtmi_pt_run of >= 6 sweeps times a sweep of each --
+    // a persistent kernel is the wrong choice when other processes share the GPU: its waiting workgroups get
+    // time-sliced against them), 0 = per-slot launches, 1 = persistent launch.  RTMI_PT_PERSISTENT=0 / 1 decides up front.
+    int engine = -1;
     unsigned int *d_sync = nullptr;  // flag[nchains] | count[nchains] | abort
     PtDev *d_ptdev = nullptr;        // device copy of `d` (the persistent kernel's step reads it from memory)
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
@@ -245,7 +250,9 @@ int enqueue_sweep(rtmi_pt *h, int nslots_k)
     return RTMI_OK;
 }
 
-int sweep_once(rtmi_pt *h)
+// engine: 0 per-slot launches, 1 the persistent launch (falls back if refused).  ev0 / ev1 (may be NULL) are recorded on the
+// stream right around the sweep's launches.
+int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *slots_out = nullptr)
 {
     // perturbation slots cover every node a chain can have during this sweep: k grows by at most one per sweep
     const int kmax = h->d.pr.kmax;
@@ -253,7 +260,21 @@ int sweep_once(rtmi_pt *h)
     if (ks > kmax)
         ks = kmax;
     h->kbound = ks;
-    if (h->use_persistent && h->d_sync && h->d_ptdev) {
+    if (slots_out)
+        *slots_out = 2 * ks;
+    struct Closer {  // records ev1 however the function is left
+        hipEvent_t e;
+        hipStream_t s;
+        ~Closer()
+        {
+            if (e)
+                (void)hipEventRecord(e, s);
+        }
+    };
+    if (engine == 1 && h->use_persistent && h->d_sync && h->d_ptdev) {
+        if (ev0)
+            HIP_TRY(hipEventRecord(ev0, h->stream));
+        Closer closer{ev1, h->stream};
         rtmi::PtSweepArgs w;
         memset(&w, 0, sizeof w);
         w.nslots_k = ks;
@@ -271,10 +292,16 @@ int sweep_once(rtmi_pt *h)
             return RTMI_OK;
         }
         h->use_persistent = false;
+        h->engine = 0;
+        closer.e = nullptr;
     }
     h->launches += 2 * ks;
-    if (!h->use_graph)
+    if (!h->use_graph) {
+        if (ev0)
+            HIP_TRY(hipEventRecord(ev0, h->stream));
+        Closer closer{ev1, h->stream};
         return enqueue_sweep(h, ks);
+    }
     auto it = h->graphs.find(ks);
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -290,6 +317,9 @@ int sweep_once(rtmi_pt *h)
         HIP_TRY(hipGraphDestroy(graph));
         it = h->graphs.emplace(ks, exec).first;
     }
+    if (ev0)
+        HIP_TRY(hipEventRecord(ev0, h->stream));
+    Closer closer{ev1, h->stream};
     HIP_TRY(hipGraphLaunch(it->second, h->stream));
     return RTMI_OK;
 }
@@ -376,8 +406,10 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     h->nsrc = c.set_n;
     if (const char *e = getenv("RTMI_PT_GRAPH"))
         h->use_graph = strcmp(e, "0") != 0;
-    if (const char *e = getenv("RTMI_PT_PERSISTENT"))
+    if (const char *e = getenv("RTMI_PT_PERSISTENT")) {
         h->use_persistent = strcmp(e, "0") != 0;
+        h->engine = h->use_persistent ? 1 : 0;
+    }
     const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n;
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
     const size_t nf64 = 4 * nc * K + 5 * nc + 2 * nc * ldm;
@@ -766,10 +798,50 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     HIP_TRY(hipSetDevice(h->device));
     if (record_every > 0 && !h->d_s_count)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: record_every > 0 needs rtmi_pt_sample_buffer first");
+    // Undecided engine: sweeps 0..5 of the first long enough call are persistent (one warm, two timed) and per-slot (one
+    // warm, two timed); then ONE event synchronisation, and the persistent launch stays unless it took more than 1.08x the
+    // time per proposal slot (its fixed cost weighs more in these first, short sweeps; the case to catch is a GPU shared
+    // with other processes, where it is several times slower).  The chains do not depend on the engine (bit-identical),
+    // so the trial is ordinary work.
+    const bool trial = h->engine < 0 && h->use_persistent && nsweeps >= 8;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int trial_slots[4] = {1, 1, 1, 1};
+    if (trial)
+        for (auto &e : ev)
+            HIP_TRY(hipEventCreate(&e));  // (eight: two per timed sweep)
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard()
+        {
+            for (int i = 0; i < 8; ++i)
+                if (e[i])
+                    (void)hipEventDestroy(e[i]);
+        }
+    } ev_guard{ev};
     for (int s = 0; s < nsweeps; ++s) {
-        int rc = sweep_once(h);
+        int rc;
+        if (trial && s < 6) {
+            // s = 0, 3: warm; s = 1, 2 -> timed pair 0, 1 (persistent); s = 4, 5 -> timed pair 2, 3 (per-slot launches)
+            const int t = s % 3 == 0 ? -1 : (s < 3 ? s - 1 : s - 2);
+            rc = sweep_once(h, s < 3 ? 1 : 0, t >= 0 ? ev[2 * t] : nullptr, t >= 0 ? ev[2 * t + 1] : nullptr,
+                            t >= 0 ? &trial_slots[t] : nullptr);
+        } else {
+            rc = sweep_once(h, h->engine == 1 ? 1 : 0);
+        }
         if (rc)
             return rc;
+        if (trial && s == 5 && h->engine < 0) {
+            float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            HIP_TRY(hipEventSynchronize(ev[7]));
+            for (int t = 0; t < 4; ++t)
+                HIP_TRY(hipEventElapsedTime(&ms[t], ev[2 * t], ev[2 * t + 1]));
+            const float per_p = (ms[0] + ms[1]) / (float)(trial_slots[0] + trial_slots[1]);
+            const float per_g = (ms[2] + ms[3]) / (float)(trial_slots[2] + trial_slots[3]);
+            h->engine = per_p <= 1.08f * per_g ? 1 : 0;
+            if (getenv("RTMI_PT_VERBOSE"))
+                fprintf(stderr, "rtmi: sweep engines timed: persistent %.1f us per slot, per-slot launches %.1f us per slot -> %s\n",
+                        1e3 * per_p, 1e3 * per_g, h->engine ? "persistent" : "per-slot launches");
+        }
         ++h->sweeps_done;
         if (swap_every > 0 && h->sweeps_done % swap_every == 0) {
             rc = swap_round_locked(h, comm);
