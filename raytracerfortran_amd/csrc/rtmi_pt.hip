@@ -803,7 +803,10 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     // time per proposal slot (its fixed cost weighs more in these first, short sweeps; the case to catch is a GPU shared
     // with other processes, where it is several times slower).  The chains do not depend on the engine (bit-identical),
     // so the trial is ordinary work.
+    // The window opens at the first sweep with at least five node slots (sweeps of one or two node slots are too short
+    // to tell: the cooperative launch has the larger fixed cost) and six more sweeps to go.
     const bool trial = h->engine < 0 && h->use_persistent && nsweeps >= 8;
+    int t0 = -1;  // first sweep of the window
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int trial_slots[4] = {1, 1, 1, 1};
     if (trial)
@@ -820,17 +823,23 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     } ev_guard{ev};
     for (int s = 0; s < nsweeps; ++s) {
         int rc;
-        if (trial && s < 6) {
-            // s = 0, 3: warm; s = 1, 2 -> timed pair 0, 1 (persistent); s = 4, 5 -> timed pair 2, 3 (per-slot launches)
-            const int t = s % 3 == 0 ? -1 : (s < 3 ? s - 1 : s - 2);
-            rc = sweep_once(h, s < 3 ? 1 : 0, t >= 0 ? ev[2 * t] : nullptr, t >= 0 ? ev[2 * t + 1] : nullptr,
+        if (trial && t0 < 0 && h->engine < 0 && nsweeps - s >= 6) {
+            const int kmax = h->d.pr.kmax, ks_next = h->kbound + 1 < kmax ? h->kbound + 1 : kmax;
+            if (ks_next >= (kmax < 5 ? kmax : 5))
+                t0 = s;
+        }
+        if (t0 >= 0 && s - t0 < 6 && h->engine < 0) {
+            // window sweeps 0, 3: warm; 1, 2 -> timed pair 0, 1 (persistent); 4, 5 -> timed pair 2, 3 (per-slot launches)
+            const int u = s - t0;
+            const int t = u % 3 == 0 ? -1 : (u < 3 ? u - 1 : u - 2);
+            rc = sweep_once(h, u < 3 ? 1 : 0, t >= 0 ? ev[2 * t] : nullptr, t >= 0 ? ev[2 * t + 1] : nullptr,
                             t >= 0 ? &trial_slots[t] : nullptr);
         } else {
             rc = sweep_once(h, h->engine == 1 ? 1 : 0);
         }
         if (rc)
             return rc;
-        if (trial && s == 5 && h->engine < 0) {
+        if (t0 >= 0 && s - t0 == 5 && h->engine < 0) {
             float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             HIP_TRY(hipEventSynchronize(ev[7]));
             for (int t = 0; t < 4; ++t)
