@@ -283,7 +283,10 @@ using namespace rtmi_host;
 
 namespace {
 
-#define RTMI_SMALL_CALL_NSRC 4096  // dff_ / TraceRays calls up to this size run on a mapped pinned buffer
+// dff_ / TraceRays calls up to this size run on a mapped pinned buffer (no copy commands).  Measured per call
+// (profiles/r02m/small_threshold.txt): 1e4 sources 61 us against 122 us through the copy pipeline, 1e5 sources 145 against
+// 179 us; at 2e5 the pipeline wins (218 against 268 us).  RTMI_SMALL_CALL_NSRC overrides.
+#define RTMI_SMALL_CALL_NSRC 131072
 
 int grow(double **p, size_t *cap, size_t need)
 {
@@ -358,12 +361,28 @@ int lane_ready(DropinLane &L, int device, size_t nevents)
     return RTMI_OK;
 }
 
+// Sources per chunk of the pipeline for a slice of n sources: an eighth of the slice, between 262 144 (below that the
+// fused kernel no longer fills the chip and the per-copy cost of ~10 us shows: 1e6 sources 0.55 ms with 4 chunks, 0.65 ms
+// with 8) and 1 048 576 (1e7 sources: 3.4 ms with chunks of 1 M, 3.7 ms with 4 M -- the first upload and the last
+// download are not overlapped -- and 5.5 ms with 262 144; profiles/r02m/dropin_modes_1e7.txt).
+int64_t dropin_chunk_for(int64_t n)
+{
+    if (g_dropin.chunk > 0)
+        return g_dropin.chunk;
+    int64_t c = (n / 8 + 65535) / 65536 * 65536;
+    if (c < 262144)
+        c = 262144;
+    if (c > 1048576)
+        c = 1048576;
+    return c;
+}
+
 void parse_dropin_env_locked(Context &c)
 {
     if (g_dropin.parsed)
         return;
     g_dropin.parsed = true;
-    g_dropin.chunk = 262144;
+    g_dropin.chunk = 0;  // 0: chosen per call from the slice length (dropin_chunk_for)
     if (const char *e = getenv("RTMI_DROPIN_CHUNK"))
         if (atoll(e) >= 4096)
             g_dropin.chunk = atoll(e) / 64 * 64;
@@ -499,10 +518,11 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
     HIP_TRY(hipSetDevice(c.device));
     const bool want_p = keep_delta > 0;
     const size_t n = (size_t)nsrc;
-    if (nsrc <= RTMI_SMALL_CALL_NSRC) {
-        // Small calls (the reference's own example has NSrc = 20): the kernel reads the model and the sources from,
-        // and writes the times to, ONE pinned host buffer mapped into the GPU's address space -- no copy commands,
-        // the call costs one launch and one stream synchronise.
+    static const int small_call_nsrc = getenv("RTMI_SMALL_CALL_NSRC") ? atoi(getenv("RTMI_SMALL_CALL_NSRC")) : RTMI_SMALL_CALL_NSRC;
+    if (nsrc <= small_call_nsrc) {
+        // Small and medium calls (the reference's own example has NSrc = 20, its sampler calls TraceRays with 1e4): the
+        // kernel reads the model and the sources from, and writes the times to, ONE pinned host buffer mapped into the
+        // GPU's address space -- no copy commands, the call costs two host memcpy, one launch and one stream synchronise.
         const size_t nm = (size_t)2 * nlayers + 1;
         const size_t need = nm + 4 * n;
         if (c.small_cap < need) {
@@ -556,7 +576,7 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
         DropinLane *L = g_dropin.lanes[(size_t)i].get();
         auto job = [=, &tn, &errs, &p]() {
             const int r = run_slice(*L, dev, vels, depths, nlayers, src_offset + k0, src_depth + k0, k1 - k0, timeP + k0,
-                                    want_p ? p.data() + k0 : nullptr, g_dropin.chunk, tn);
+                                    want_p ? p.data() + k0 : nullptr, dropin_chunk_for(k1 - k0), tn);
             if (r)
                 errs[(size_t)i] = g_err;  // the worker thread's message
             return r;

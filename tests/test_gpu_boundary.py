@@ -82,10 +82,10 @@ def test_two_threads_call_dff_concurrently(rt, O):
         rt.set_option("refill_min", 32)
 
 
-@pytest.mark.parametrize("n", [4097, 262144, 262145, 1_000_000])
+@pytest.mark.parametrize("n", [4097, 131072, 131073, 262145, 1_000_000, 2_500_000])
 def test_chunked_dropin_pipeline_sizes(rt, O, n):
-    """dff_ above the small-call limit: chunks of 262144 sources through the upload / kernel / download queues, ragged
-    last chunk, rays.dat (keep_delta > 0) assembled from the chunks' final ray parameters."""
+    """dff_ around and above the mapped-buffer limit (131072 sources): one chunk, then chunks of an eighth of the call
+    (at least 262144 sources) through the upload / kernel / download queues, ragged last chunk."""
     rng = np.random.default_rng(n)
     v, d = random_model(rng, 8)
     off, dep = rng.uniform(10, 8000, n), rng.uniform(20, d[-1] + 400, n)
@@ -111,7 +111,7 @@ def test_sharded_dropin_two_pipelines(tmp_path):
         "    ref = O.oracle_dff(v, d, off, dep)\n"
         "    assert np.array_equal(t, ref), n\n"
         "print('sharded ok')\n")
-    env = dict(os.environ, RTMI_DEVICES="0,0,0", RTMI_SHARD_MIN="4000", RTMI_DROPIN_CHUNK="65536")
+    env = dict(os.environ, RTMI_DEVICES="0,0,0", RTMI_SHARD_MIN="4000", RTMI_DROPIN_CHUNK="65536", RTMI_SMALL_CALL_NSRC="4096")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
     assert p.returncode == 0 and "sharded ok" in p.stdout, p.stderr[-2000:]
 
