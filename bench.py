@@ -215,10 +215,16 @@ def dropin_figures(rt, v, d, off, dep, ref_t=None):
     med20, best20 = median_ms(small, 300, 20)
     out["dff_nsrc20_us"] = med20 * 1e3
     out["dff_nsrc20_best_us"] = best20 * 1e3
+    if off.size >= 10_000:
+        # the size of the reference sampler's own TraceRays calls (loglhood.f90:135 with NSRC = 1e4): the mapped-buffer path
+        mid, _ = caller(d.size, np.ascontiguousarray(off[:10_000]), np.ascontiguousarray(dep[:10_000]))
+        med1e4, _ = median_ms(mid, 100, 10)
+        out["dff_nsrc1e4_us"] = med1e4 * 1e3
     out["devices"] = os.environ.get("RTMI_DEVICES", "bound device only")
     out["note"] = ("host buffers in, host buffers out through the C symbol dff_ (pageable memory, PCIe inclusive); "
                    "median of 15 calls at the bench size on the same arrays (a Fortran caller's static buffers), of 8 calls on "
-                   "newly allocated arrays (R's .Fortran copies), of 300 calls at the reference's example size NSrc = 20")
+                   "newly allocated arrays (R's .Fortran copies), of 300 calls at the reference's example size NSrc = 20, of 100 calls at "
+                   "NSrc = 1e4")
     return out
 
 
