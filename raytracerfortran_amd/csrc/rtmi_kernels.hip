@@ -1405,7 +1405,7 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     int threads = 0;
     const int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
                                        &a.slots, &lds_bytes);
-    const bool verbose = getenv("RTMI_PT_VERBOSE") != nullptr;
+    static const bool verbose = getenv("RTMI_PT_VERBOSE") != nullptr;  // read once
     ws.lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
     lds_bytes = (size_t)ws.lds_ctl + 16;
     if (gx != ws.gx || lds_bytes > 160 * 1024 || threads < 64 || ws.nchains != nchains) {
