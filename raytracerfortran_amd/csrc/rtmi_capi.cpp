@@ -180,7 +180,8 @@ int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
 
 int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
-                 const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream)
+                 const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream,
+                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop)
 {
     const Tuning tn = tuning_snapshot();
     int *d_status = nullptr;
@@ -207,6 +208,11 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
         fa.d_timeP = d_timeP;
         fa.d_obs = d_obs;
         fa.d_partial = d_partial;
+        if (d_inc && d_r2cur && d_r2prop && d_obs && !d_timeP) {
+            fa.d_inc = d_inc;
+            fa.d_r2cur = d_r2cur;
+            fa.d_r2prop = d_r2prop;
+        }
         HIP_TRY(rtmi_launch_fused(&fa, nmodels, max_nlayers, cus, tn.solve_waves, &gx, stream));
     } else {
         rtmi::TraceArgs a;
@@ -237,7 +243,7 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
 int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
-                    const void *sweep_args, hipStream_t stream)
+                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop)
 {
     const rtmi::PtSweepArgs *w = static_cast<const rtmi::PtSweepArgs *>(sweep_args);
     const Tuning tn = tuning_snapshot();
@@ -267,6 +273,11 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
     fa.nsrc = nsrc;
     fa.d_obs = d_obs;
     fa.d_partial = d_partial;
+    if (d_inc && d_r2cur && d_r2prop) {
+        fa.d_inc = d_inc;
+        fa.d_r2cur = d_r2cur;
+        fa.d_r2prop = d_r2prop;
+    }
     const hipError_t e = rtmi_launch_pt_sweep(&fa, ptdev, ptdev_bytes, w, nchains, max_nlayers, cus, tn.solve_waves, stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // not sticky: the caller falls back

@@ -38,6 +38,22 @@ struct TraceArgsT {
 };
 typedef TraceArgsT<double> TraceArgs;
 
+// Incremental likelihood of the tempering sampler (fused kernel, double precision, with d_obs): a proposal changes the
+// model only from some depth `zthr` downwards, and a source above it has the stack, hence the travel time and the
+// squared residual, it has under the chain's current model -- bit for bit, so that value is taken from r2cur instead of
+// being traced again.  One record per model row, written by the sampler's step:
+//   zthr, dl1, dl2   the proposal being evaluated: sources with z < zthr, z != dl1, z != dl2 are unaffected (dl1 / dl2 =
+//                    the last interface of the current / the proposed model: whichLayer's special case for a source exactly
+//                    on the LAST interface, subroutineR-quiet.f90:22-30, makes such a source depend on which interface is last)
+//   pending, p*      an accepted proposal whose residuals still sit in r2prop: every launch first moves the residuals of
+//                    the sources THAT proposal affected to r2cur (each source by the thread that loads it)
+struct PtInc {
+    double zthr, dl1, dl2;
+    double pzthr, pdl1, pdl2;
+    int pending;
+    int pad_;
+};
+
 // Arguments of the fused large-NSrc kernel.  Model m = blockIdx.y uses row m of d_vels / d_depths.
 #define RTMI_SLOT_BYTES(T) (3 * sizeof(T) + 10)  // LDS per queued record: offset, depth, p + key, nl scratch (u32) + order (u16)
 template <typename T>
@@ -65,6 +81,8 @@ struct FusedArgsT {
                                    // out (bits 1, 2, 4) or a d_nlayers[m] was out of range (bit 8)
     int max_nlayers;               // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers]
     int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
+    const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_obs, T = double
+    T *d_r2cur, *d_r2prop;         // [nmodels][nsrc] squared residuals under the current model / of the proposal
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };

@@ -214,6 +214,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_CLASSES 4             // RTMI_TRIP_CLASSES classes of bisection sources + the Newton-only class
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
+#define RTMI_RK_CACHED 0x10000000u    // rk: incremental likelihood -- the source is not affected by the proposal: rR holds its squared residual
 #define RTMI_RK_DONE 0x40000000u      // rk: p_final is in rp (set by the first evaluation, or when the solve loop finishes the source)
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
@@ -236,6 +237,15 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     a.d_depths += (int64_t)m * a.ld_model;
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
+    // incremental likelihood (PtInc in rtmi_kernels.h): this model's record and residual rows
+    constexpr bool INC = WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;
+    const bool inc = INC && a.d_inc != nullptr;
+    PtInc ic = {};
+    if (inc) {
+        ic = a.d_inc[m];
+        a.d_r2cur += (int64_t)m * a.nsrc;
+        a.d_r2prop += (int64_t)m * a.nsrc;
+    }
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index: scalar
     const int nwib = blockDim.x >> 6;
@@ -384,6 +394,19 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
             const uint32_t pos = hist[wib * 64 + bin_of(nl, nl_max)] + (packed >> 11);
             if (valid) {
+                bool cached = false;
+                T r2c = T(0.0);
+                if (inc) {
+                    // residuals of the last accepted proposal that are still in r2prop: this source's moves to r2cur now
+                    const bool moved = ic.pending && !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
+                    cached = nl > 1 && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+                    if (moved) {
+                        r2c = a.d_r2prop[k];
+                        a.d_r2cur[k] = r2c;
+                    } else if (cached) {
+                        r2c = a.d_r2cur[k];
+                    }
+                }
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
                     const T tt = straight_time(z, R, t.V[0]);
@@ -394,7 +417,17 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     if (WANT_SS) {
                         const T r = a.d_obs[k] - tt;
                         ss = ss + r * r;
+                        if (inc)
+                            a.d_r2prop[k] = r * r;
                     }
+                } else if (cached) {
+                    // not affected by the proposal: a finished record that carries its squared residual (it keeps its place
+                    // in the slot order, so the sum below is the one a full evaluation makes)
+                    rR[pos] = r2c;
+                    rz[pos] = z;
+                    rp[pos] = T(0.0);
+                    rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT) | RTMI_RK_CACHED | RTMI_RK_DONE |
+                              RTMI_RK_CONV;
                 } else {
                     rR[pos] = R;
                     rz[pos] = z;
@@ -423,20 +456,21 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             const T p0 = valid ? rp[q] : T(0.0);
             lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
             lane_start(s, p0);
-            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
+            const bool cached = INC && (key & RTMI_RK_CACHED) != 0u;
+            const bool live = valid && !cached && (p0 == p0);  // NaN p0: the reference never returns -> -999
             if (!live)
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
-            T f, fp;
-            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
-            {
+            T f = T(0.0), fp = T(1.0);
+            if (!INC || __any(live)) {  // a chunk of unaffected sources (they are the shallow ones: whole chunks) costs nothing
+                eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
                 // every lane of the wave takes part (wave-uniform choice of the divide); dead lanes are restored
                 const Lane<T> keep = s;
                 lane_advance_init(s, f, fp, live);
                 if (!live)
                     s = keep;
             }
-            if (valid) {
+            if (valid && !cached) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
                     rp[q] = s.x;
@@ -859,14 +893,18 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     pending &= ~(1u << j);
                     progress = true;
                     const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-                    const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
-                    const T p = valid ? rp[q] : T(0.0);
-                    const T z = valid ? rz[q] : T(1.0);
-                    const int nfw = wave_max_i32(valid ? il : 0);
-                    T tt = travel_time(t, p, il, nfw, il, z, valid);
+                    // incremental likelihood: an unaffected source already carries its squared residual in rR
+                    const bool comp = valid && !(INC && (key & RTMI_RK_CACHED) != 0u);
+                    if (INC && !__any(comp))
+                        continue;
+                    const int il = comp ? (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1 : 1;
+                    const T p = comp ? rp[q] : T(0.0);
+                    const T z = comp ? rz[q] : T(1.0);
+                    const int nfw = wave_max_i32(comp ? il : 0);
+                    T tt = travel_time(t, p, il, nfw, il, z, comp);
                     if (!(key & RTMI_RK_CONV))
                         tt = -T(999.0);
-                    if (valid) {
+                    if (comp) {
                         const int loc = (int)(key & RTMI_RK_LOC_MASK);
                         const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
                         if (WANT_T)
@@ -876,6 +914,8 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                         if (WANT_SS) {
                             const T r = a.d_obs[k] - tt;
                             rR[q] = r * r;  // the record's R is not needed any more
+                            if (inc)
+                                a.d_r2prop[k] = r * r;
                         }
                     }
                 }

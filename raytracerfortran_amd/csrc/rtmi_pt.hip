@@ -76,6 +76,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
     R::sorted_order(qz, k, ord);
     d.NL[c] = R::pack_model(qz, qv, k, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
     d.pactive[c] = 2;
+    d.inc[c].zthr = -INFINITY;  // every source is evaluated (and the residual cache filled)
+    d.inc[c].dl1 = d.inc[c].dl2 = 0.0;
 }
 
 // Temperature exchange: logL, levels and the ladder are staged in LDS, thread 0 runs the shared deterministic pairing
@@ -187,6 +189,11 @@ struct rtmi_pt {
     int engine = -1;
     unsigned int *d_sync = nullptr;  // flag[nchains] | count[nchains] | abort
     PtDev *d_ptdev = nullptr;        // device copy of `d` (the persistent kernel's step reads it from memory)
+    // incremental likelihood: squared residuals of every chain under its current model / under the proposal being evaluated
+    double *d_r2 = nullptr;          // [2][nchains][nsrc]
+    rtmi::PtInc *d_inc = nullptr;    // [nchains] what the step tells the likelihood about each chain's proposal
+    int *d_cache_valid = nullptr;    // [nchains]
+    bool incremental = true;         // RTMI_PT_INCREMENTAL=0: every proposal is evaluated over all sources
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
     int64_t launches = 0, models = 0;
@@ -217,8 +224,10 @@ int launch_likelihood(rtmi_pt *h)
 {
     int gx = 0;
     const size_t n = (size_t)h->nsrc;
+    const size_t r2n = (size_t)h->nchains * n;
     int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
-                          nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream);
+                          nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream,
+                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr);
     if (rc)
         return rc;
     if (gx != h->d.gx)
@@ -285,8 +294,10 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         w.count = h->d_sync + h->nchains;
         w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
         const size_t n = (size_t)h->nsrc;
+        const size_t r2n = (size_t)h->nchains * n;
         if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
-                            h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream) == RTMI_OK) {
+                            h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream,
+                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr) == RTMI_OK) {
             h->epoch += 2u * (unsigned int)ks;
             h->launches += 1;
             return RTMI_OK;
@@ -406,6 +417,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     h->nsrc = c.set_n;
     if (const char *e = getenv("RTMI_PT_GRAPH"))
         h->use_graph = strcmp(e, "0") != 0;
+    if (const char *e = getenv("RTMI_PT_INCREMENTAL"))
+        h->incremental = strcmp(e, "0") != 0;
     if (const char *e = getenv("RTMI_PT_PERSISTENT")) {
         h->use_persistent = strcmp(e, "0") != 0;
         h->engine = h->use_persistent ? 1 : 0;
@@ -421,9 +434,15 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_u64, 9 * nc * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&h->d_partial, nc * (size_t)gx * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_logpk, ((size_t)prior->kmax + 2) * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess;
+              hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_inc, nc * sizeof(rtmi::PtInc)) == hipSuccess &&
+              hipMalloc((void **)&h->d_cache_valid, nc * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) == hipSuccess;
     if (ok)
-        ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess;
+        ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_inc, 0, nc * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_cache_valid, 0, nc * sizeof(int), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess;
     if (ok) {
         // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
         ok = hipMemcpyAsync(h->d_set, c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) == hipSuccess &&
@@ -471,6 +490,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.ctr = h->d_u64;
         d.stats = (long long *)(h->d_u64 + nc);
         d.partial = h->d_partial;
+        d.inc = h->d_inc;
+        d.cache_valid = h->d_cache_valid;
         // every chain starts as a half-space at the middle of the velocity prior, sigma 0.01, beta 1 (as the host
         // engine of round 1 did); rtmi_pt_set_chain overrides
         std::vector<double> init(nc * K, 0.0), sd0(nc, 0.01), b0(nc, 1.0);
@@ -504,7 +525,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
     for (auto &g : h->graphs)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
-                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev};
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -525,6 +546,9 @@ int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const 
     HIP_TRY(hipMemcpyAsync(h->d.sd + c, &sd, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d.beta + c, &beta, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d.k + c, &k, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    // the residual cache belongs to the model that was here: invalid until a model of this chain has been evaluated in full
+    HIP_TRY(hipMemsetAsync(h->d_cache_valid + c, 0, sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_inc + c, 0, sizeof(rtmi::PtInc), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (k > h->kbound)
         h->kbound = k;

@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/rtmi.h"
+#include "rtmi_kernels.h"
 #include "rtmi_pt_rules.h"
 
 namespace rtmi_pt_dev {
@@ -34,6 +35,9 @@ struct PtDev {
     int32_t *NL;          // 0 = inactive row
     const double *partial;  // [nchains][gx]
     long long *stats;     // [nchains][8]: acc/prop birth-death, acc/prop perturbation, acc/prop sigma, models evaluated, -
+    // incremental likelihood (rtmi_kernels.h::PtInc): what the step tells the likelihood about each chain's proposal
+    rtmi::PtInc *inc;     // [nchains]
+    int *cache_valid;     // [nchains] r2cur holds the residuals of the chain's current model (cleared by rtmi_pt_set_chain)
 };
 
 #define PT_STEP_THREADS 256
@@ -72,6 +76,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     const unsigned long long ctr0 = d.ctr[c];
     double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
     const double beta = d.beta[c], plp = d.plp[c];
+    const rtmi::PtInc ic = d.inc[c];  // of the proposal that has just been evaluated (if any)
+    int cache_ok = d.cache_valid[c];
     double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
     if (decide != PT_NONE && act != 0)
         for (int j = 0; j < d.gx; ++j)
@@ -82,6 +88,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
     if (decide != PT_NONE && act != 0) {
         const double logl_new = R::gaussian_loglike(part, d.ndata, sd);
+        bool took = act == 2;  // the evaluated model is (now) the chain's current model
         if (act == 2) {
             ss = part;
             logL = logl_new;
@@ -105,10 +112,26 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                     d.z[row] = zi;
                     d.v[row] = vi;
                 }
+                took = true;
             }
         }
-        if (lead)
+        if (lead) {
             d.pactive[c] = 0;
+            // The launch that evaluated this model has moved the residuals of an earlier accepted proposal to r2cur.  If
+            // this one is taken, ITS residuals (in r2prop, for the sources it affected) are the pending ones now; a model
+            // that was evaluated in full makes the cache valid.
+            rtmi::PtInc *o = d.inc + c;
+            o->pending = took ? 1 : 0;
+            if (took) {
+                o->pzthr = ic.zthr;
+                o->pdl1 = ic.dl1;
+                o->pdl2 = ic.dl2;
+                if (ic.zthr == -INFINITY && !cache_ok)
+                    d.cache_valid[c] = 1;
+            }
+        }
+        if (took && ic.zthr == -INFINITY)
+            cache_ok = 1;
     }
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
@@ -153,6 +176,19 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                                      : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
     const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
                                      : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
+    // Incremental likelihood: the proposal changes the model from depth zthr downwards (the new node, the removed node,
+    // the shallower of a moved node's two depths, the top of the layer whose velocity changes); dl1 / dl2 = the last
+    // interface of the current / the proposed model (9999.9 for a half-space, as LOGLHOOD_RT passes it).
+    auto group_max = [&](double x) {
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1)
+            x = fmax(x, __shfl_xor(x, off, 64));
+        return x;
+    };
+    const double zi0 = zi;  // this lane's node depth before the move
+    const double dl_cur = k == 1 ? 9999.9 : group_max((i >= 1 && i < k) ? zi : -INFINITY);
+    int moved_node = 0;     // death: the removed node; perturbation: the node
+    double zthr = -INFINITY;
     int qk = k;
     double lp = 0.0;
     bool have = false;
@@ -177,6 +213,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 qk = k + 1;
                 lp = lpk_kp - lpk_k;
                 have = true;
+                zthr = zn;
             } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
                 int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
                 if (idel > k - 1)
@@ -188,6 +225,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 qk = k - 1;
                 lp = lpk_km - lpk_k;
                 have = true;
+                moved_node = idel;
+                zthr = INFINITY;  // = the removed node's depth: taken from its lane below
             }
         }
     } else if (ivo < k) {
@@ -201,6 +240,16 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 vi += step;
         }
         have = true;
+        moved_node = ivo;
+        zthr = INFINITY;      // = min(old, new depth) of the node (a velocity leaves the depth as it is): from its lane below
+    }
+    {
+        const double z_old = __shfl(zi0, gbase + (moved_node & (G - 1)), 64);
+        const double z_new = __shfl(zi, gbase + (moved_node & (G - 1)), 64);
+        if (zthr == INFINITY)
+            zthr = (propose == PT_BD) ? z_old : fmin(z_old, z_new);
+        if (!cache_ok || !(zthr == zthr))
+            zthr = -INFINITY;  // no valid cache yet (or a NaN depth): evaluate in full
     }
     // CHECKBOUNDS (prjmh_temper_rf.f90:1639-1679; rtmi_pt_rules.h::inside_bounds) over the qk proposed nodes
     const bool in = have && i < qk;
@@ -219,6 +268,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
             prev = zj;
     }
     bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
+    const double dl_all = group_max((in && i >= 1) ? zi : -INFINITY);
+    const double dl_new = qk == 1 ? 9999.9 : dl_all;
     const bool ok = have && (__ballot(bad) & gmask) == 0ull;
     int nl = 0;
     if (ok) {
@@ -247,6 +298,10 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
             d.plp[c] = lp;
             d.pactive[c] = 1;
             st[6] += 1;  // a model that goes through the likelihood
+            rtmi::PtInc *o = d.inc + c;
+            o->zthr = zthr;
+            o->dl1 = dl_cur;
+            o->dl2 = dl_new;
         }
     } else if (have && lead) {
         st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""tests/soak_pt.py [ncases] -- the sampler's two sweep engines against each other on random shapes (not collected by
-pytest; run on the GPU box): chains x sources x kmax x seed drawn at random, sweeps with exchanges and recorded samples,
-every chain / statistic / ladder / sample bit-identical between the per-slot launches and the persistent launch, and the
-logL of every final state equal to the oracle's (1e-9 relative)."""
+"""tests/soak_pt.py [ncases] -- the sampler's sweep engines and its incremental likelihood against the plain form on random
+shapes (not collected by pytest; run on the GPU box): chains x sources x kmax x seed drawn at random, sweeps with
+exchanges and recorded samples; every chain / statistic / ladder / sample bit-identical between
+  per-slot launches, every proposal evaluated over all sources      (RTMI_PT_PERSISTENT=0 RTMI_PT_INCREMENTAL=0)
+  per-slot launches, unaffected sources taken from the residual cache (0, 1)
+  the persistent launch with the cache                                 (1, 1)
+and the logL of sampled final states equal to the oracle's (1e-9 relative)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,8 +29,9 @@ for case in range(ncases):
     nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])[: min(7, kmax)]
     pr = T.Prior(kmax=kmax)
     res = {}
-    for engine in ("0", "1"):
+    for engine, incr in (("0", "0"), ("0", "1"), ("1", "1")):
         os.environ["RTMI_PT_PERSISTENT"] = engine
+        os.environ["RTMI_PT_INCREMENTAL"] = incr
         h = raymod.NativeChains(nch, kmax + 1, n, pr, seed=seed)
         for i in range(nch):
             h.set_chain(i, nodes, 0.016, 1.0)
@@ -36,16 +40,18 @@ for case in range(ncases):
         h.set_ladder(nch, 0, np.arange(nch) % nlev, 1.15 ** -np.arange(float(nlev)))
         h.sample_buffer(4096)
         h.run(sweeps, 1, None, 3)
-        res[engine] = (h.get_all(), h.stats(), h.get_ladder()[0], h.samples())
+        res[engine + incr] = (h.get_all(), h.stats(), h.get_ladder()[0], h.samples())
         del h
-    (a0, s0, l0, m0), (a1, s1, l1, m1) = res["0"], res["1"]
+    (a0, s0, l0, m0) = res["00"]
+    for other in ("01", "11"):
+        (a1, s1, l1, m1) = res[other]
+        live = np.arange(a0["z"].shape[1])[None, :] < a0["k"][:, None]
+        ok = all(np.array_equal(a0[k], a1[k]) for k in ("k", "sd", "logL", "ss", "beta"))
+        ok = ok and np.array_equal(a0["z"][live], a1["z"][live]) and np.array_equal(a0["v"][live], a1["v"][live])
+        ok = ok and np.array_equal(l0, l1) and {k: v for k, v in s0.items() if k != "launches"} == {k: v for k, v in s1.items() if k != "launches"}
+        ok = ok and all(np.array_equal(m0[k], m1[k]) for k in ("sweep", "chain", "k", "sd", "logL")) and m0["dropped"] == m1["dropped"]
+        assert ok, ("variants differ", other, case, nch, n, kmax, seed)
     ran_persistent += s1["launches"] < s0["launches"]
-    live = np.arange(a0["z"].shape[1])[None, :] < a0["k"][:, None]
-    ok = all(np.array_equal(a0[k], a1[k]) for k in ("k", "sd", "logL", "ss", "beta"))
-    ok = ok and np.array_equal(a0["z"][live], a1["z"][live]) and np.array_equal(a0["v"][live], a1["v"][live])
-    ok = ok and np.array_equal(l0, l1) and {k: v for k, v in s0.items() if k != "launches"} == {k: v for k, v in s1.items() if k != "launches"}
-    ok = ok and all(np.array_equal(m0[k], m1[k]) for k in ("sweep", "chain", "k", "sd", "logL")) and m0["dropped"] == m1["dropped"]
-    assert ok, ("engines differ", case, nch, n, kmax, seed)
     for i in rng.choice(nch, 3, replace=False):
         k = int(a1["k"][i])
         v, d = T.layering(np.column_stack([a1["z"][i, :k], a1["v"][i, :k]]))

@@ -464,8 +464,10 @@ def test_device_sweep_config4_miniature_k_up_to_30():
 
 
 @pytest.mark.gpu
-def test_persistent_sweep_equals_the_per_slot_launches():
-    """The two engines of the device-resident sweep -- two launches per proposal slot (replayed as a hipGraph) and ONE
+def test_persistent_sweep_and_incremental_likelihood_equal_the_plain_form():
+    """The incremental likelihood (a proposal changes the model from some depth downwards; the sources above it keep the
+    squared residuals of the chain's current model, bit for bit, so they are read from a cache instead of being traced)
+    and the two engines of the device-resident sweep -- two launches per proposal slot (replayed as a hipGraph) and ONE
     persistent cooperative launch per sweep whose workgroups meet chain by chain (csrc/rtmi_kernels.hip::pt_sweep_kernel)
     -- run the same step function and the same likelihood body: every chain, its statistics and the ladder must be
     bit-identical after sweeps with exchanges.  The launch counter tells which engine ran."""
@@ -479,22 +481,39 @@ def test_persistent_sweep_equals_the_per_slot_launches():
     nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
     out = {}
     old = os.environ.get("RTMI_PT_PERSISTENT")
+    old_inc = os.environ.get("RTMI_PT_INCREMENTAL")
     try:
-        for engine in ("0", "1"):
-            os.environ["RTMI_PT_PERSISTENT"] = engine
+        # "0": per-slot launches, every proposal evaluated over ALL sources (the plain form of the algorithm);
+        # "1": the persistent launch with the incremental likelihood (sources above the depth a proposal changes keep their
+        # residuals from the cache); "inc": per-slot launches with the incremental likelihood
+        for engine in ("0", "1", "inc"):
+            os.environ["RTMI_PT_PERSISTENT"] = "1" if engine == "1" else "0"
+            os.environ["RTMI_PT_INCREMENTAL"] = "0" if engine == "0" else "1"
             h = raymod.NativeChains(nch, 11, n, T.Prior(), seed=21)
+            # a third of the chains start with their LAST interface exactly at a source's depth, a third with an inner
+            # interface at one: whichLayer's special case (subroutineR-quiet.f90:22-30) is what the cache's dl1 / dl2 rule covers
+            j_last = int(np.argmin(np.where(dep > 3970.0, dep, np.inf)))
+            j_in = int(np.argmin(np.abs(dep - 2000.0)))
+            nodes_last, nodes_in = nodes.copy(), nodes.copy()
+            nodes_last[-1, 0] = dep[j_last]
+            nodes_in[3, 0] = dep[j_in]
             for i in range(nch):
-                h.set_chain(i, nodes, 0.016, 1.0)
+                h.set_chain(i, (nodes, nodes_last, nodes_in)[i % 3], 0.016, 1.0)
             h.evaluate()
             h.set_ladder(nch, 0, np.arange(nch) // 2, 1.15 ** -np.arange(16.0))
             h.run(25, 1, None, 0)
             out[engine] = (h.get_all(), h.stats(), h.get_ladder()[0])
             del h
     finally:
-        if old is None:
-            os.environ.pop("RTMI_PT_PERSISTENT", None)
-        else:
-            os.environ["RTMI_PT_PERSISTENT"] = old
+        for name, val in (("RTMI_PT_PERSISTENT", old), ("RTMI_PT_INCREMENTAL", old_inc)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+    (a0, s0, l0), (a2, s2, l2) = out["0"], out["inc"]
+    for key in ("k", "sd", "logL", "ss", "beta"):
+        assert np.array_equal(a0[key], a2[key]), ("incremental likelihood", key)
+    assert np.array_equal(l0, l2) and s0 == s2
     (a0, s0, l0), (a1, s1, l1) = out["0"], out["1"]
     if s1["launches"] >= s0["launches"]:
         pytest.skip("the cooperative launch was refused on this device: the per-slot launches ran twice")
