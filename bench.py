@@ -380,7 +380,11 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                                     + ("one persistent cooperative launch per sweep" if launches <= 2 * max(1, args.steps)
                                        else "two launches per proposal slot, replayed as a hipGraph") + ", swap exchange: "
                                     + ("RCCL all-gather" if s.comm is not None else ("local" if world == 1 else "host gather (gloo rehearsal)")),
-                          "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"])}}
+                          "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"]),
+                          "likelihood": ("full: every proposal traced over all sources" if os.environ.get("RTMI_PT_INCREMENTAL") == "0"
+                                         else "incremental: sources above the depth a proposal changes keep the residuals of the "
+                                              "chain's current model (bit-identical); value counts the travel times a full "
+                                              "evaluation delivers (models x sources), not only the re-traced ones")}}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

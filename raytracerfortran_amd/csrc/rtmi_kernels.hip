@@ -225,7 +225,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // template parameter so that each instantiation holds one form of the evaluation loop only (code size).
 // The body is a device function of (model m, workgroup row bx of gx rows): the kernel below calls it with the launch's
 // grid indices, the persistent sweep kernel of the tempering sampler (pt_sweep_kernel) once per proposal slot.
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, bool ROWS>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, bool ROWS, bool INCR = false>
 __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const int bx, const int gx, T *lds)
 {
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
     // incremental likelihood (PtInc in rtmi_kernels.h): this model's record and residual rows
-    constexpr bool INC = WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;
+    constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
     const bool inc = INC && a.d_inc != nullptr;
     PtInc ic = {};
     if (inc) {
@@ -959,12 +959,12 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     }
 }
 
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false, bool INCR = false>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
-    fused_body<T, WANT_P, WANT_T, WANT_SS, DIAG, ROWS>(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x,
-                                                       reinterpret_cast<T *>(lds_raw));
+    fused_body<T, WANT_P, WANT_T, WANT_SS, DIAG, ROWS, INCR>(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x,
+                                                             reinterpret_cast<T *>(lds_raw));
 }
 
 // ---- the tempering sampler's sweep as ONE persistent launch ---------------------------------------------------------
@@ -1027,7 +1027,7 @@ __device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chai
     }
 }
 
-template <bool ROWS>
+template <bool ROWS, bool INCR>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, PtSweepArgs w)
 {
     using namespace rtmi_pt_dev;
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArg
                 return;
             __builtin_amdgcn_s_dcache_inv();
         }
-        fused_body<double, false, false, true, false, ROWS>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
+        fused_body<double, false, false, true, false, ROWS, INCR>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
         __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
         if (threadIdx.x == 0) {
             __threadfence();
@@ -1353,6 +1353,12 @@ static hipError_t prepare_fused_t()
     if (e == hipSuccess)
         e = set_fused_lds_limit<T, false, false, true>();
     if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
         attr_set = true;
     return e;
 }
@@ -1403,7 +1409,13 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     } while (0)
     if (want_ss && want_t)
         RTMI_LAUNCH_FUSED(false, true, true, false);
-    else if (want_ss)
+    else if (want_ss && a.d_inc && std::is_same<T, double>::value) {
+        // the tempering sampler's incremental likelihood (PtInc): its own instantiation
+        if (a.rows)
+            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, true, true>), grid, block, lds_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, false, true>), grid, block, lds_bytes, stream, a);
+    } else if (want_ss)
         RTMI_LAUNCH_FUSED(false, false, true, false);
     else if (want_p)
         RTMI_LAUNCH_FUSED(true, true, false, false);
@@ -1456,8 +1468,10 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     // one round per evaluation only: a chain's share of the sources must fit the workgroup's LDS (it does for every
     // shape the per-slot launches run in one round; otherwise leave it to them)
     ws.xcd_map = (nchains % 8 == 0) ? 1 : 0;  // measured: 1.18 ms per sweep against 1.21 with a chain spread over the XCDs
-    const void *fn = a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true>)
-                            : reinterpret_cast<const void *>(&pt_sweep_kernel<false>);
+    const void *fn = a.d_inc ? (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, true>)
+                                       : reinterpret_cast<const void *>(&pt_sweep_kernel<false, true>))
+                             : (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, false>)
+                                       : reinterpret_cast<const void *>(&pt_sweep_kernel<false, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
         return e;
