@@ -336,7 +336,7 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                          torch.tensor(off, device=dev), torch.tensor(dep, device=dev)).cpu().numpy()
     ev = T.GpuEvaluator(off, dep, tt + rng.normal(0, 0.016, nsrc))
     nloc = 32
-    s = T.NativeSampler(T.Prior(), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
+    s = T.NativeSampler(T.Prior(kmax=args.kmax), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
                   rank=rank, world=world, dist=dist if world > 1 else None,
                   dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)
@@ -372,8 +372,8 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "ranks": world, "devices": args.devices, "collective_backend": args.backend,
-               "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,10], "
-                                      "swap round every sweep (BASELINE configs 3/4 shape)" % nsrc,
+               "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,%d], "
+                                      "swap round every sweep (BASELINE configs 3/4 shape)" % (nsrc, args.kmax),
                           "chains": nloc * world, "models_evaluated": models,
                           "launches_per_step": launches / max(1, args.steps),
                           "engine": "device-resident sweep (rtmi_pt_run), "
@@ -396,6 +396,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nsrc", type=int, default=1_000_000)
+    ap.add_argument("--kmax", type=int, default=10, help="pt: largest number of nodes of a chain (config 3: 10, config 4: 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive drop-in figures (c2 only)")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
