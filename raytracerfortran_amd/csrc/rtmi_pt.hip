@@ -6,18 +6,23 @@
 //   TEMPSWP_MH            temperature exchange between two chains                   prjmh_temper_rf.f90:1329-1357
 // with LOGLHOOD -> TraceRays behind every decision (loglhood.f90:128-199).
 //
-// Here the chains of one process (one GPU) advance in lock-step and NOTHING of a sweep runs on the host:
+// Here the chains of one process (one GPU) live on the GPU and NOTHING of a sweep runs on the host:
 //   * chain state (k, node depths and velocities, sigma, logL, SS, beta, the position of the chain's random stream)
 //     lives in HBM for the lifetime of the handle;
-//   * a proposal slot is two launches on one stream: pt_step_kernel (one lane group per chain: accept/reject the
-//     previous slot from the residual sums the likelihood launch left behind, then draw this slot's proposal, check
-//     CHECKBOUNDS and write the proposed model as a row of the batch) and the batched likelihood launch of
-//     rtmi_kernels.hip over the handle's resident sources (rows of chains without a valid proposal are marked
-//     inactive and cost nothing);
-//   * a sweep = birth/death slot + one slot per (node, parameter) + the sigma move, captured once per slot count
-//     as a hipGraph and replayed; the temperature exchange is one all-gather of logL (RCCL, rtmi_comm.cpp) plus
-//     pt_swap_kernel, and pt_record_kernel appends the T = 1 chains to a sample ring -- so rtmi_pt_run enqueues whole
-//     runs without a single host synchronisation.
+//   * a proposal slot is a step (rtmi_pt_dev.hpp::pt_step_group, one lane group per chain: accept/reject the previous
+//     slot from the residual sums the likelihood left behind, then draw this slot's proposal, check CHECKBOUNDS and
+//     write the proposed model as a row of the batch) and the likelihood of every proposed model over the handle's
+//     resident sources (fused kernel body of rtmi_kernels.hip; rows of chains without a valid proposal are inactive);
+//   * the likelihood is incremental: the step also tells it from which depth downwards the proposal changes the model
+//     (rtmi_kernels.h::PtInc); sources above keep the squared residuals of the chain's current model, which live in
+//     HBM next to the chain (r2cur / r2prop) -- bit-identical to evaluating every proposal over all sources;
+//   * a sweep = birth/death slot + one slot per (node, parameter) + the sigma move.  Two engines, same chains: ONE
+//     persistent cooperative launch whose workgroups meet chain by chain (rtmi_kernels.hip::pt_sweep_kernel), or two
+//     launches per slot (pt_step_kernel + the batched likelihood launch) captured once per slot count as a hipGraph and
+//     replayed; the first long rtmi_pt_run times both and keeps the faster (rtmi_pt_run below);
+//   * the temperature exchange is one all-gather of logL (RCCL, rtmi_comm.cpp) plus pt_swap_kernel, and
+//     pt_record_kernel appends the T = 1 chains to a sample ring -- so rtmi_pt_run enqueues whole runs without a host
+//     synchronisation (but for the one of the engine trial, once per handle).
 // The rules themselves (proposals, prior, bounds, acceptance, pairing) are in rtmi_pt_rules.h, shared with the host.
 #include <hip/hip_runtime.h>
 
