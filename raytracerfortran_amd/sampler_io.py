@@ -146,9 +146,12 @@ def run_from_files(directory: str, nsweeps: int, nchains: int = 8, seed: int = 1
         return {"logL": T.gaussian_loglike(ss, obs.size, sd), "pred": pred}
     prior = T.Prior(kmin=par["NLMN"], kmax=par["NLMX"], lam=par["lambda"], hmx=par["hmx"], hmin=par["hmin"],
                     sdmin=par["sdmn"][1], sdmax=par["sdmx"][1])  # RT data use the second entry (read_input.f90:234-236)
+    # without an injected likelihood the sweeps, exchanges and the sample bookkeeping run inside librtmi.so on the GPU
+    # (tempering.NativeSampler -> rtmi_pt_run); an injected evaluator (CPU tests) drives the per-chain Python engine
     ev = evaluator or T.GpuEvaluator(off, dep, obs, ld=max(32, par["NLMX"] + 2))
-    s = T.Sampler(prior, ev, ndata=obs.size, nchains_total=nchains, nptchains1=par["NPTCHAINS1"], dTlog=par["dTlog"],
-                  seed=seed)
+    engine = T.Sampler if evaluator is not None else T.NativeSampler
+    s = engine(prior, ev, ndata=obs.size, nchains_total=nchains, nptchains1=par["NPTCHAINS1"], dTlog=par["dTlog"],
+               seed=seed)
     s.init_from_model(nodes, sd)
     samples = s.run(nsweeps, burnin=burnin, thin=par["ICHAINTHIN"])
     with open(out_base + "_voro_sample.txt", "w") as f:
