@@ -356,9 +356,11 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
 
     run_steps(args.warmup)
     st0 = s.native.stats()
+    tr0, ca0 = s.native.likelihood_counts()
     elapsed, _ = timed_steps(None, args.steps, 0, world, dist if world > 1 else None, dev,
                              sync=torch.cuda.synchronize, run_steps=run_steps)
     st1 = s.native.stats()
+    tr1, ca1 = s.native.likelihood_counts()
     models = st1["models"] - st0["models"]
     launches = st1["launches"] - st0["launches"]
     s.sync()
@@ -381,6 +383,7 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                                        else "two launches per proposal slot, replayed as a hipGraph") + ", swap exchange: "
                                     + ("RCCL all-gather" if s.comm is not None else ("local" if world == 1 else "host gather (gloo rehearsal)")),
                           "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"]),
+                          "sources_retraced_fraction": ((tr1 - tr0) / max(1, (tr1 - tr0) + (ca1 - ca0))) if (tr1 - tr0) + (ca1 - ca0) > 0 else 1.0,
                           "likelihood": ("full: every proposal traced over all sources" if os.environ.get("RTMI_PT_INCREMENTAL") == "0"
                                          else "incremental: sources above the depth a proposal changes keep the residuals of the "
                                               "chain's current model (bit-identical); value counts the travel times a full "

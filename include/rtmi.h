@@ -149,6 +149,8 @@ int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* = rtmi_pt_run(h, nsweeps, 0, NU
 /* out8: accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, likelihood launches,
  * models evaluated */
 int rtmi_pt_stats(const rtmi_pt *h, int64_t *out8);
+/* incremental likelihood: sources of proposals traced / taken from the residual cache so far */
+int rtmi_pt_likelihood_counts(const rtmi_pt *h, int64_t *traced, int64_t *cached);
 
 /*
  * Temperature ladder and exchange.  level[c] = temperature level of GLOBAL chain c (replicated on every rank),

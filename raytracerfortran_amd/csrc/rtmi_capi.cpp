@@ -181,7 +181,7 @@ int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
 int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
                  const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream,
-                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop)
+                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop, unsigned long long *d_inc_counts)
 {
     const Tuning tn = tuning_snapshot();
     int *d_status = nullptr;
@@ -212,6 +212,7 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
             fa.d_inc = d_inc;
             fa.d_r2cur = d_r2cur;
             fa.d_r2prop = d_r2prop;
+            fa.d_inc_counts = d_inc_counts;
         }
         HIP_TRY(rtmi_launch_fused(&fa, nmodels, max_nlayers, cus, tn.solve_waves, &gx, stream));
     } else {
@@ -243,7 +244,8 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
 int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
-                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop)
+                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop,
+                    unsigned long long *d_inc_counts)
 {
     const rtmi::PtSweepArgs *w = static_cast<const rtmi::PtSweepArgs *>(sweep_args);
     const Tuning tn = tuning_snapshot();
@@ -277,6 +279,7 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
         fa.d_inc = d_inc;
         fa.d_r2cur = d_r2cur;
         fa.d_r2prop = d_r2prop;
+        fa.d_inc_counts = d_inc_counts;
     }
     const hipError_t e = rtmi_launch_pt_sweep(&fa, ptdev, ptdev_bytes, w, nchains, max_nlayers, cus, tn.solve_waves, stream);
     if (e != hipSuccess) {

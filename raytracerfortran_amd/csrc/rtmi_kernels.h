@@ -83,6 +83,7 @@ struct FusedArgsT {
     int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
     const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_obs, T = double
     T *d_r2cur, *d_r2prop;         // [nmodels][nsrc] squared residuals under the current model / of the proposal
+    unsigned long long *d_inc_counts;  // [nmodels][grid.x][2] or NULL: sources traced / taken from the cache, added up over the launches
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };

@@ -241,6 +241,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
     const bool inc = INC && a.d_inc != nullptr;
     PtInc ic = {};
+    unsigned int n_cached = 0, n_traced = 0;  // this thread's sources (statistics of the incremental likelihood)
     if (inc) {
         ic = a.d_inc[m];
         a.d_r2cur += (int64_t)m * a.nsrc;
@@ -406,6 +407,8 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     } else if (cached) {
                         r2c = a.d_r2cur[k];
                     }
+                    n_cached += cached ? 1u : 0u;
+                    n_traced += cached ? 0u : 1u;
                 }
                 if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
@@ -941,20 +944,43 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             stamps[3] = clock64();
     }
 
+    const bool counting = INC && inc && a.d_inc_counts != nullptr;
+    if (counting) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            n_cached += __shfl_xor(n_cached, off, 64);
+            n_traced += __shfl_xor(n_traced, off, 64);
+        }
+    }
     if (WANT_SS) {
         // workgroup reduction in a fixed order: lanes by xor-butterfly, then waves 0..nwib-1
         T *wsum = rR;  // the record area is free now (the round loop ended with a barrier)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             ss = ss + __shfl_xor(ss, off, 64);
-        if (lane == 0)
+        if (lane == 0) {
             wsum[wib] = ss;
+            if (counting) {  // statistics: this workgroup's own two words, no atomics (launches of a handle are stream-ordered)
+                wsum[32 + 2 * wib] = (T)n_traced;
+                wsum[33 + 2 * wib] = (T)n_cached;
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             T tot = wsum[0];
             for (int w = 1; w < nwib; ++w)
                 tot = tot + wsum[w];
             a.d_partial[(int64_t)m * gx + bx] = tot;
+            if (counting) {
+                unsigned long long tr = 0, ca = 0;
+                for (int w = 0; w < nwib; ++w) {
+                    tr += (unsigned long long)wsum[32 + 2 * w];
+                    ca += (unsigned long long)wsum[33 + 2 * w];
+                }
+                unsigned long long *o = a.d_inc_counts + 2 * ((int64_t)m * gx + bx);
+                o[0] += tr;
+                o[1] += ca;
+            }
         }
     }
 }

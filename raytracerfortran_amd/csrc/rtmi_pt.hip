@@ -198,6 +198,7 @@ struct rtmi_pt {
     double *d_r2 = nullptr;          // [2][nchains][nsrc]
     rtmi::PtInc *d_inc = nullptr;    // [nchains] what the step tells the likelihood about each chain's proposal
     int *d_cache_valid = nullptr;    // [nchains]
+    unsigned long long *d_inc_counts = nullptr;  // [nchains][gx][2] sources traced / taken from the cache (statistics)
     bool incremental = true;         // RTMI_PT_INCREMENTAL=0: every proposal is evaluated over all sources
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -232,7 +233,7 @@ int launch_likelihood(rtmi_pt *h)
     const size_t r2n = (size_t)h->nchains * n;
     int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                           nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream,
-                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr);
+                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr, h->d_inc_counts);
     if (rc)
         return rc;
     if (gx != h->d.gx)
@@ -302,7 +303,8 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         const size_t r2n = (size_t)h->nchains * n;
         if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                             h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream,
-                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr) == RTMI_OK) {
+                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr,
+                            h->d_inc_counts) == RTMI_OK) {
             h->epoch += 2u * (unsigned int)ks;
             h->launches += 1;
             return RTMI_OK;
@@ -442,11 +444,13 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess &&
               hipMalloc((void **)&h->d_inc, nc * sizeof(rtmi::PtInc)) == hipSuccess &&
               hipMalloc((void **)&h->d_cache_valid, nc * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_inc_counts, 2 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) == hipSuccess;
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_inc, 0, nc * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_cache_valid, 0, nc * sizeof(int), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_inc_counts, 0, 2 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess;
     if (ok) {
         // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
@@ -530,7 +534,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
     for (auto &g : h->graphs)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
-                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2};
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -915,6 +919,28 @@ int rtmi_pt_stats(const rtmi_pt *hc, int64_t *out8)
     }
     out8[6] = h->launches;
     out8[7] += h->models;  // + the models of rtmi_pt_evaluate
+    return RTMI_OK;
+}
+
+// Sources the likelihood launches of this handle have traced / have taken from the residual cache so far (sources of
+// proposals only; the incremental likelihood off: cached stays 0 and traced is not counted).
+int rtmi_pt_likelihood_counts(const rtmi_pt *hc, int64_t *traced, int64_t *cached)
+{
+    rtmi_pt *h = const_cast<rtmi_pt *>(hc);
+    if (!h || !traced || !cached)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_likelihood_counts: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> c((size_t)2 * h->nchains * h->d.gx);  // one pair per workgroup
+    HIP_TRY(hipMemcpy(c.data(), h->d_inc_counts, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long tr = 0, ca = 0;
+    for (size_t i = 0; i + 1 < c.size(); i += 2) {
+        tr += c[i];
+        ca += c[i + 1];
+    }
+    *traced = (int64_t)tr;
+    *cached = (int64_t)ca;
     return RTMI_OK;
 }
 

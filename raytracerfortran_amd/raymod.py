@@ -53,6 +53,7 @@ SIGNATURES = {
     "rtmi_pt_evaluate": (ctypes.c_int, [_vp]),
     "rtmi_pt_sweep": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rtmi_pt_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_likelihood_counts": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_set_ladder": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]),
     "rtmi_pt_get_ladder": (ctypes.c_int, [_vp, _ip, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_swap_round": (ctypes.c_int, [_vp, _vp]),
@@ -390,6 +391,12 @@ class NativeChains:
             _check(-m)
         return {"sweep": sweep[:m], "chain": chain[:m], "k": k[:m], "sd": sd[:m], "logL": ll[:m], "z": z[:m], "v": v[:m],
                 "dropped": int(dropped.value)}
+
+    def likelihood_counts(self):
+        """(sources of proposals traced, sources taken from the residual cache) since the handle was created."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self.lib.rtmi_pt_likelihood_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def stats(self):
         out = (ctypes.c_int64 * 8)()
