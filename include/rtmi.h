@@ -109,8 +109,9 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
  * The likelihood of a proposal is INCREMENTAL: a birth, death or perturbation changes the model from some depth
  * downwards, and a source above that depth has, bit for bit, the travel time it has under the chain's current model --
  * its squared residual is taken from a per-chain cache in HBM (2 x nchains x ndata doubles) instead of being traced
- * again; the sum is made in the same order, so logL and the chains are those of the full evaluation
- * (RTMI_PT_INCREMENTAL=0 evaluates every proposal over all sources).
+ * again.  The sampler's sums of squared residuals are EXACT (a 192-bit fixed-point accumulator per lane, wave, workgroup),
+ * so their value does not depend on the order of the additions: logL and the chains are those of the full evaluation
+ * (RTMI_PT_INCREMENTAL=0 evaluates every proposal over all sources), whatever the launch geometry, knobs or engine.
  *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
  *   EXPLORE_MH           prjmh_temper_rf.f90:521-634   PROPOSAL_SDRT :1616   CHECKBOUNDS :1639
  *   TEMPSWP_MH           prjmh_temper_rf.f90:1329-1357 (replaces the pairing through rank 0, :331-349)

@@ -166,6 +166,11 @@ static bool batch_takes_fused(const Tuning &tn, int64_t nsrc)
     return tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC / 4 || tn.force_path == 2);
 }
 
+bool batch_is_fused(int64_t nsrc)
+{
+    return batch_takes_fused(tuning_snapshot(), nsrc);
+}
+
 int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
 {
     const Tuning tn = tuning_snapshot();
@@ -181,7 +186,8 @@ int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
 int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
                  const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream,
-                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop, unsigned long long *d_inc_counts)
+                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop, unsigned long long *d_inc_counts,
+                 unsigned long long *d_partial_x)
 {
     const Tuning tn = tuning_snapshot();
     int *d_status = nullptr;
@@ -208,11 +214,14 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
         fa.d_timeP = d_timeP;
         fa.d_obs = d_obs;
         fa.d_partial = d_partial;
-        if (d_inc && d_r2cur && d_r2prop && d_obs && !d_timeP) {
-            fa.d_inc = d_inc;
-            fa.d_r2cur = d_r2cur;
-            fa.d_r2prop = d_r2prop;
-            fa.d_inc_counts = d_inc_counts;
+        if (d_partial_x && d_obs && !d_timeP) {  // the sampler's form of the sums (exact), optionally incremental
+            fa.d_partial_x = d_partial_x;
+            if (d_inc && d_r2cur && d_r2prop) {
+                fa.d_inc = d_inc;
+                fa.d_r2cur = d_r2cur;
+                fa.d_r2prop = d_r2prop;
+                fa.d_inc_counts = d_inc_counts;
+            }
         }
         HIP_TRY(rtmi_launch_fused(&fa, nmodels, max_nlayers, cus, tn.solve_waves, &gx, stream));
     } else {
@@ -245,7 +254,7 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
                     const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop,
-                    unsigned long long *d_inc_counts)
+                    unsigned long long *d_inc_counts, unsigned long long *d_partial_x)
 {
     const rtmi::PtSweepArgs *w = static_cast<const rtmi::PtSweepArgs *>(sweep_args);
     const Tuning tn = tuning_snapshot();
@@ -275,7 +284,8 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
     fa.nsrc = nsrc;
     fa.d_obs = d_obs;
     fa.d_partial = d_partial;
-    if (d_inc && d_r2cur && d_r2prop) {
+    fa.d_partial_x = d_partial_x;
+    if (d_partial_x && d_inc && d_r2cur && d_r2prop) {
         fa.d_inc = d_inc;
         fa.d_r2cur = d_r2cur;
         fa.d_r2prop = d_r2prop;

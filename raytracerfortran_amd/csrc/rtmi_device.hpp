@@ -642,6 +642,83 @@ __device__ __forceinline__ bool term_guarded_n(const float (&w)[N], const float 
 __device__ __forceinline__ int hi_word(double v) { return __double2hiint(v); }
 __device__ __forceinline__ int hi_word(float v) { return (int)__float_as_uint(v); }
 
+// ---- exact accumulation of squared residuals (the sampler's likelihood) -----------------------------------------------
+// A 192-bit fixed-point accumulator, least significant bit 2^-128, 64 integer bits: adding non-negative doubles below 2^43
+// to it is EXACT down to 2^-128 (a squared residual of 3e-39 s^2), and integer addition is associative -- the sum of a
+// chain's squared residuals does not depend on the order in which lanes, waves, workgroups or launches of different
+// geometry add them up, nor on whether a residual was computed in this launch or taken from the chain's cache.  flags: 1 a
+// NaN was added (the sum is NaN, as the reference's SUM would be), 2 a term >= 2^43 s^2 (the sum is reported as +Inf).
+struct Acc192 {
+    unsigned long long w0, w1, w2;
+    unsigned int flags;
+};
+
+__device__ __forceinline__ Acc192 acc_zero()
+{
+    Acc192 a;
+    a.w0 = a.w1 = a.w2 = 0ull;
+    a.flags = 0u;
+    return a;
+}
+
+__device__ __forceinline__ void acc_add_words(Acc192 &a, unsigned long long b0, unsigned long long b1, unsigned long long b2)
+{
+    unsigned long long t = a.w0 + b0;
+    const unsigned long long c0 = t < b0 ? 1ull : 0ull;
+    a.w0 = t;
+    t = a.w1 + b1;
+    unsigned long long c1 = t < b1 ? 1ull : 0ull;
+    const unsigned long long t2 = t + c0;
+    c1 |= t2 < c0 ? 1ull : 0ull;
+    a.w1 = t2;
+    a.w2 = a.w2 + b2 + c1;
+}
+
+__device__ __forceinline__ void acc_add(Acc192 &a, const Acc192 &b)
+{
+    acc_add_words(a, b.w0, b.w1, b.w2);
+    a.flags |= b.flags;
+}
+
+// a += x for a squared residual x (>= 0, or NaN)
+__device__ __forceinline__ void acc_add_double(Acc192 &a, double x)
+{
+    if (!(x >= 0.0)) {
+        a.flags |= 1u;
+        return;
+    }
+    if (x >= 8796093022208.0) {  // 2^43
+        a.flags |= 2u;
+        return;
+    }
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const int e = (int)((bits >> 52) & 0x7FFull);
+    if (e == 0)
+        return;  // zero or subnormal: below 2^-128
+    unsigned long long m = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;  // x = m 2^(e - 1075)
+    int shift = e - 947;                                                      // position of m's lowest bit above 2^-128
+    if (shift < 0) {
+        if (shift <= -53)
+            return;
+        m >>= -shift;
+        shift = 0;
+    }
+    const int idx = shift >> 6, s = shift & 63;  // idx 0 or 1 (x < 2^43)
+    const unsigned long long lo = m << s, hi = s ? (m >> (64 - s)) : 0ull;
+    acc_add_words(a, idx == 0 ? lo : 0ull, idx == 0 ? hi : lo, idx == 0 ? 0ull : hi);
+}
+
+// the accumulated sum as a double: a fixed function of the exact integer
+__device__ __forceinline__ double acc_to_double(const Acc192 &a)
+{
+    if (a.flags & 1u)
+        return __builtin_nan("");
+    if (a.flags & 2u)
+        return __builtin_inf();
+    const double lo = __ull2double_rn(a.w1) * 5.421010862427522e-20 + __ull2double_rn(a.w0) * 2.938735877055719e-39;  // 2^-64, 2^-128
+    return __ull2double_rn(a.w2) + lo;
+}
+
 // lower end of the guarded range of w = 1 - p^2 v^2
 template <typename T>
 __device__ __forceinline__ constexpr T guard_w()

@@ -78,7 +78,9 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                  double *d_timeP, const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out,
                  hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2cur = nullptr, double *d_r2prop = nullptr,
-                 unsigned long long *d_inc_counts = nullptr);
+                 unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr);
+// whether launch_batch takes the fused kernel for this many sources (current knobs)
+bool batch_is_fused(int64_t nsrc);
 // workgroups per model (= partial sums per model) launch_batch will use for this shape
 int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus);
 // The tempering sampler's sweep as one persistent cooperative launch (rtmi_kernels.hip::pt_sweep_kernel): the batched
@@ -88,7 +90,8 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
                     const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2cur = nullptr,
-                    double *d_r2prop = nullptr, unsigned long long *d_inc_counts = nullptr);
+                    double *d_r2prop = nullptr, unsigned long long *d_inc_counts = nullptr,
+                    unsigned long long *d_partial_x = nullptr);
 
 }  // namespace rtmi_host
 

@@ -81,7 +81,10 @@ struct FusedArgsT {
                                    // out (bits 1, 2, 4) or a d_nlayers[m] was out of range (bit 8)
     int max_nlayers;               // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers]
     int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
-    const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_obs, T = double
+    unsigned long long *d_partial_x;  // [nmodels][grid.x][4] or NULL: the SAMPLER's form of the sums -- per workgroup an exact
+                                      // 192-bit fixed-point sum of squared residuals (rtmi_device.hpp::Acc192: words 0..2, flags)
+                                      // instead of d_partial; needs d_obs, no d_timeP, T = double, the fused kernel
+    const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_partial_x
     T *d_r2cur, *d_r2prop;         // [nmodels][nsrc] squared residuals under the current model / of the proposal
     unsigned long long *d_inc_counts;  // [nmodels][grid.x][2] or NULL: sources traced / taken from the cache, added up over the launches
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL

@@ -214,7 +214,6 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_CLASSES 4             // RTMI_TRIP_CLASSES classes of bisection sources + the Newton-only class
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
-#define RTMI_RK_CACHED 0x10000000u    // rk: incremental likelihood -- the source is not affected by the proposal: rR holds its squared residual
 #define RTMI_RK_DONE 0x40000000u      // rk: p_final is in rp (set by the first evaluation, or when the solve loop finishes the source)
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
@@ -228,18 +227,27 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, bool ROWS, bool INCR = false>
 __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const int bx, const int gx, T *lds)
 {
+    // INC: the sampler's form of the likelihood -- squared residuals are accumulated EXACTLY (Acc192, rtmi_device.hpp), so
+    // the sum does not depend on who adds what in which order, and (with a.d_inc) unaffected sources come from the cache
+    constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
     if (a.d_nlayers && reject_model_row<T>(a.nlayers, a.max_nlayers, a.allow_skip, a.d_status,
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
-                                           WANT_SS ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx))
+                                           (WANT_SS && !INC) ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx)) {
+        if (INC && threadIdx.x == 0) {
+            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
+            o[0] = o[1] = o[2] = 0ull;
+            o[3] = (a.allow_skip && a.nlayers == 0) ? 0ull : 1ull;  // an unusable row: NaN, like the plain form
+        }
         return;
+    }
     a.d_vels += (int64_t)m * a.ld_model;
     a.d_depths += (int64_t)m * a.ld_model;
     if (WANT_T)
         a.d_timeP += (int64_t)m * a.nsrc;
     // incremental likelihood (PtInc in rtmi_kernels.h): this model's record and residual rows
-    constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
     const bool inc = INC && a.d_inc != nullptr;
+    Acc192 acc = acc_zero();  // (INC) this thread's squared residuals
     PtInc ic = {};
     unsigned int n_cached = 0, n_traced = 0;  // this thread's sources (statistics of the incremental likelihood)
     if (inc) {
@@ -326,7 +334,10 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             const bool valid = k < a.nsrc;
             const T z = z_next;
             z_next = depth_of(j0, c + nwib);
-            int nl = which_layer(t, a.nlayers, z);
+            // incremental likelihood: a source the proposal does not affect is neither located nor sorted (its squared
+            // residual is added from the cache in the second pass)
+            const bool unaffected = inc && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+            int nl = unaffected ? 1 : which_layer(t, a.nlayers, z);
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
             const int bin = bin_of(nl, nl_max);
@@ -400,7 +411,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 if (inc) {
                     // residuals of the last accepted proposal that are still in r2prop: this source's moves to r2cur now
                     const bool moved = ic.pending && !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
-                    cached = nl > 1 && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+                    cached = (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;  // as in the first pass
                     if (moved) {
                         r2c = a.d_r2prop[k];
                         a.d_r2cur[k] = r2c;
@@ -410,7 +421,10 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     n_cached += cached ? 1u : 0u;
                     n_traced += cached ? 0u : 1u;
                 }
-                if (nl == 1) {
+                if (cached) {
+                    if constexpr (INC)
+                        acc_add_double(acc, (double)r2c);  // not affected by the proposal: its residual under the current model
+                } else if (nl == 1) {
                     // straight ray in the top layer (:94-97): finished here
                     const T tt = straight_time(z, R, t.V[0]);
                     if (WANT_T)
@@ -419,18 +433,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                         a.d_p_final[k] = __builtin_nan("");
                     if (WANT_SS) {
                         const T r = a.d_obs[k] - tt;
-                        ss = ss + r * r;
-                        if (inc)
-                            a.d_r2prop[k] = r * r;
+                        if constexpr (INC) {
+                            acc_add_double(acc, (double)(r * r));
+                            if (inc)
+                                a.d_r2prop[k] = r * r;
+                        } else {
+                            ss = ss + r * r;
+                        }
                     }
-                } else if (cached) {
-                    // not affected by the proposal: a finished record that carries its squared residual (it keeps its place
-                    // in the slot order, so the sum below is the one a full evaluation makes)
-                    rR[pos] = r2c;
-                    rz[pos] = z;
-                    rp[pos] = T(0.0);
-                    rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT) | RTMI_RK_CACHED | RTMI_RK_DONE |
-                              RTMI_RK_CONV;
                 } else {
                     rR[pos] = R;
                     rz[pos] = z;
@@ -459,21 +469,20 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             const T p0 = valid ? rp[q] : T(0.0);
             lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
             lane_start(s, p0);
-            const bool cached = INC && (key & RTMI_RK_CACHED) != 0u;
-            const bool live = valid && !cached && (p0 == p0);  // NaN p0: the reference never returns -> -999
+            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
             if (!live)
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
-            T f = T(0.0), fp = T(1.0);
-            if (!INC || __any(live)) {  // a chunk of unaffected sources (they are the shallow ones: whole chunks) costs nothing
-                eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            T f, fp;
+            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            {
                 // every lane of the wave takes part (wave-uniform choice of the divide); dead lanes are restored
                 const Lane<T> keep = s;
                 lane_advance_init(s, f, fp, live);
                 if (!live)
                     s = keep;
             }
-            if (valid && !cached) {
+            if (valid) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
                     rp[q] = s.x;
@@ -896,18 +905,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     pending &= ~(1u << j);
                     progress = true;
                     const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-                    // incremental likelihood: an unaffected source already carries its squared residual in rR
-                    const bool comp = valid && !(INC && (key & RTMI_RK_CACHED) != 0u);
-                    if (INC && !__any(comp))
-                        continue;
-                    const int il = comp ? (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1 : 1;
-                    const T p = comp ? rp[q] : T(0.0);
-                    const T z = comp ? rz[q] : T(1.0);
-                    const int nfw = wave_max_i32(comp ? il : 0);
-                    T tt = travel_time(t, p, il, nfw, il, z, comp);
+                    const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
+                    const T p = valid ? rp[q] : T(0.0);
+                    const T z = valid ? rz[q] : T(1.0);
+                    const int nfw = wave_max_i32(valid ? il : 0);
+                    T tt = travel_time(t, p, il, nfw, il, z, valid);
                     if (!(key & RTMI_RK_CONV))
                         tt = -T(999.0);
-                    if (comp) {
+                    if (valid) {
                         const int loc = (int)(key & RTMI_RK_LOC_MASK);
                         const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
                         if (WANT_T)
@@ -916,9 +921,13 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                             a.d_p_final[k] = p;
                         if (WANT_SS) {
                             const T r = a.d_obs[k] - tt;
-                            rR[q] = r * r;  // the record's R is not needed any more
-                            if (inc)
-                                a.d_r2prop[k] = r * r;
+                            if constexpr (INC) {
+                                acc_add_double(acc, (double)(r * r));
+                                if (inc)
+                                    a.d_r2prop[k] = r * r;
+                            } else {
+                                rR[q] = r * r;  // the record's R is not needed any more
+                            }
                         }
                     }
                 }
@@ -933,7 +942,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             }
         }
         __syncthreads();
-        if (WANT_SS) {
+        if (WANT_SS && !INC) {
             // the squared residuals, added up in SLOT order by all waves: an order that depends on nothing but the
             // sources and the launch geometry (not on the scheduling knobs, not on which chunk was ready first)
             for (int q = wib * 64 + lane; q < nq; q += nwib * 64)
@@ -944,43 +953,70 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             stamps[3] = clock64();
     }
 
-    const bool counting = INC && inc && a.d_inc_counts != nullptr;
-    if (counting) {
+    if constexpr (INC) {
+        // The sampler's form: exact sums (Acc192) -- butterfly over the lanes, the waves through LDS, one record of four
+        // words per workgroup; any order would give the same words.  Statistics ride along (no atomics: the launches of a
+        // handle are stream-ordered and every workgroup owns its words).
+        const bool counting = inc && a.d_inc_counts != nullptr;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
+            Acc192 o;
+            o.w0 = __shfl_xor(acc.w0, off, 64);
+            o.w1 = __shfl_xor(acc.w1, off, 64);
+            o.w2 = __shfl_xor(acc.w2, off, 64);
+            o.flags = __shfl_xor(acc.flags, off, 64);
+            acc_add(acc, o);
             n_cached += __shfl_xor(n_cached, off, 64);
             n_traced += __shfl_xor(n_traced, off, 64);
         }
-    }
-    if (WANT_SS) {
+        unsigned long long *wx = reinterpret_cast<unsigned long long *>(rR);  // the record area is free now
+        if (lane == 0) {
+            wx[6 * wib + 0] = acc.w0;
+            wx[6 * wib + 1] = acc.w1;
+            wx[6 * wib + 2] = acc.w2;
+            wx[6 * wib + 3] = acc.flags;
+            wx[6 * wib + 4] = n_traced;
+            wx[6 * wib + 5] = n_cached;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Acc192 tot = acc_zero();
+            unsigned long long tr = 0, ca = 0;
+            for (int w = 0; w < nwib; ++w) {
+                Acc192 o;
+                o.w0 = wx[6 * w + 0];
+                o.w1 = wx[6 * w + 1];
+                o.w2 = wx[6 * w + 2];
+                o.flags = (unsigned int)wx[6 * w + 3];
+                acc_add(tot, o);
+                tr += wx[6 * w + 4];
+                ca += wx[6 * w + 5];
+            }
+            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
+            o[0] = tot.w0;
+            o[1] = tot.w1;
+            o[2] = tot.w2;
+            o[3] = tot.flags;
+            if (counting) {
+                unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * gx + bx);
+                oc[0] += tr;
+                oc[1] += ca;
+            }
+        }
+    } else if (WANT_SS) {
         // workgroup reduction in a fixed order: lanes by xor-butterfly, then waves 0..nwib-1
         T *wsum = rR;  // the record area is free now (the round loop ended with a barrier)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             ss = ss + __shfl_xor(ss, off, 64);
-        if (lane == 0) {
+        if (lane == 0)
             wsum[wib] = ss;
-            if (counting) {  // statistics: this workgroup's own two words, no atomics (launches of a handle are stream-ordered)
-                wsum[32 + 2 * wib] = (T)n_traced;
-                wsum[33 + 2 * wib] = (T)n_cached;
-            }
-        }
         __syncthreads();
         if (threadIdx.x == 0) {
             T tot = wsum[0];
             for (int w = 1; w < nwib; ++w)
                 tot = tot + wsum[w];
             a.d_partial[(int64_t)m * gx + bx] = tot;
-            if (counting) {
-                unsigned long long tr = 0, ca = 0;
-                for (int w = 0; w < nwib; ++w) {
-                    tr += (unsigned long long)wsum[32 + 2 * w];
-                    ca += (unsigned long long)wsum[33 + 2 * w];
-                }
-                unsigned long long *o = a.d_inc_counts + 2 * ((int64_t)m * gx + bx);
-                o[0] += tr;
-                o[1] += ca;
-            }
         }
     }
 }
@@ -1435,8 +1471,8 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     } while (0)
     if (want_ss && want_t)
         RTMI_LAUNCH_FUSED(false, true, true, false);
-    else if (want_ss && a.d_inc && std::is_same<T, double>::value) {
-        // the tempering sampler's incremental likelihood (PtInc): its own instantiation
+    else if (want_ss && a.d_partial_x && std::is_same<T, double>::value) {
+        // the tempering sampler's form of the likelihood (exact sums, optionally incremental: PtInc): its own instantiation
         if (a.rows)
             hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, true, true>), grid, block, lds_bytes, stream, a);
         else
@@ -1494,7 +1530,7 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     // one round per evaluation only: a chain's share of the sources must fit the workgroup's LDS (it does for every
     // shape the per-slot launches run in one round; otherwise leave it to them)
     ws.xcd_map = (nchains % 8 == 0) ? 1 : 0;  // measured: 1.18 ms per sweep against 1.21 with a chain spread over the XCDs
-    const void *fn = a.d_inc ? (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, true>)
+    const void *fn = a.d_partial_x ? (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, true>)
                                        : reinterpret_cast<const void *>(&pt_sweep_kernel<false, true>))
                              : (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, false>)
                                        : reinterpret_cast<const void *>(&pt_sweep_kernel<false, false>));

@@ -199,6 +199,9 @@ struct rtmi_pt {
     rtmi::PtInc *d_inc = nullptr;    // [nchains] what the step tells the likelihood about each chain's proposal
     int *d_cache_valid = nullptr;    // [nchains]
     unsigned long long *d_inc_counts = nullptr;  // [nchains][gx][2] sources traced / taken from the cache (statistics)
+    // exact per-workgroup sums of squared residuals (Acc192), when the handle's launches take the fused kernel; NULL for
+    // source sets small enough for the plain kernel, whose sums are doubles in d_partial
+    unsigned long long *d_partial_x = nullptr;   // [nchains][gx][4]
     bool incremental = true;         // RTMI_PT_INCREMENTAL=0: every proposal is evaluated over all sources
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -228,12 +231,15 @@ void launch_step(rtmi_pt *h, int decide, int sigma, int propose, int ivo, int ip
 
 int launch_likelihood(rtmi_pt *h)
 {
+    if ((h->d_partial_x != nullptr) != batch_is_fused(h->nsrc))
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: the kernel path was changed (rtmi_set_option \"path\") while a sampler handle exists");
     int gx = 0;
     const size_t n = (size_t)h->nsrc;
     const size_t r2n = (size_t)h->nchains * n;
     int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                           nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream,
-                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr, h->d_inc_counts);
+                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr, h->d_inc_counts,
+                          h->d_partial_x);
     if (rc)
         return rc;
     if (gx != h->d.gx)
@@ -286,7 +292,7 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
                 (void)hipEventRecord(e, s);
         }
     };
-    if (engine == 1 && h->use_persistent && h->d_sync && h->d_ptdev) {
+    if (engine == 1 && h->use_persistent && h->d_sync && h->d_ptdev && h->d_partial_x) {
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
         Closer closer{ev1, h->stream};
@@ -304,7 +310,7 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                             h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream,
                             h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr,
-                            h->d_inc_counts) == RTMI_OK) {
+                            h->d_inc_counts, h->d_partial_x) == RTMI_OK) {
             h->epoch += 2u * (unsigned int)ks;
             h->launches += 1;
             return RTMI_OK;
@@ -432,6 +438,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     }
     const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n;
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
+    const bool fused_path = batch_is_fused(c.set_n);  // which kernel the handle's likelihood launches will take
     const size_t nf64 = 4 * nc * K + 5 * nc + 2 * nc * ldm;
     const size_t ni32 = 4 * nc;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -445,12 +452,14 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_inc, nc * sizeof(rtmi::PtInc)) == hipSuccess &&
               hipMalloc((void **)&h->d_cache_valid, nc * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_inc_counts, 2 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess &&
+              (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess) &&
               hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) == hipSuccess;
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_inc, 0, nc * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_cache_valid, 0, nc * sizeof(int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_inc_counts, 0, 2 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             (!h->d_partial_x || hipMemsetAsync(h->d_partial_x, 0, 4 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess) &&
              hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess;
     if (ok) {
         // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
@@ -499,6 +508,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.ctr = h->d_u64;
         d.stats = (long long *)(h->d_u64 + nc);
         d.partial = h->d_partial;
+        d.partial_x = h->d_partial_x;
         d.inc = h->d_inc;
         d.cache_valid = h->d_cache_valid;
         // every chain starts as a half-space at the middle of the velocity prior, sigma 0.01, beta 1 (as the host
@@ -534,7 +544,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
     for (auto &g : h->graphs)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
-                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts};
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);

@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/rtmi.h"
+#include "rtmi_device.hpp"
 #include "rtmi_kernels.h"
 #include "rtmi_pt_rules.h"
 
@@ -33,7 +34,8 @@ struct PtDev {
     // batch rows of the likelihood launch and its per-workgroup residual sums
     double *V, *D;        // [nchains][ld_model]
     int32_t *NL;          // 0 = inactive row
-    const double *partial;  // [nchains][gx]
+    const double *partial;  // [nchains][gx] (the plain kernel's sums: small source sets)
+    const unsigned long long *partial_x;  // [nchains][gx][4] or NULL: exact sums of the fused kernel's sampler form (Acc192)
     long long *stats;     // [nchains][8]: acc/prop birth-death, acc/prop perturbation, acc/prop sigma, models evaluated, -
     // incremental likelihood (rtmi_kernels.h::PtInc): what the step tells the likelihood about each chain's proposal
     rtmi::PtInc *inc;     // [nchains]
@@ -78,10 +80,25 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     const double beta = d.beta[c], plp = d.plp[c];
     const rtmi::PtInc ic = d.inc[c];  // of the proposal that has just been evaluated (if any)
     int cache_ok = d.cache_valid[c];
-    double part = 0.0;  // SUM(DresRT**2): the workgroups' sums in a fixed order
-    if (decide != PT_NONE && act != 0)
-        for (int j = 0; j < d.gx; ++j)
-            part = part + d.partial[(size_t)c * d.gx + j];
+    double part = 0.0;  // SUM(DresRT**2) over the workgroups' sums
+    if (decide != PT_NONE && act != 0) {
+        if (d.partial_x) {  // exact: any order gives the same words
+            rtmi::Acc192 tot = rtmi::acc_zero();
+            for (int j = 0; j < d.gx; ++j) {
+                const unsigned long long *w = d.partial_x + 4 * ((size_t)c * d.gx + j);
+                rtmi::Acc192 o;
+                o.w0 = w[0];
+                o.w1 = w[1];
+                o.w2 = w[2];
+                o.flags = (unsigned int)w[3];
+                rtmi::acc_add(tot, o);
+            }
+            part = rtmi::acc_to_double(tot);
+        } else {
+            for (int j = 0; j < d.gx; ++j)  // in a fixed order
+                part = part + d.partial[(size_t)c * d.gx + j];
+        }
+    }
     long long *st = d.stats + (size_t)c * 8;
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
 
