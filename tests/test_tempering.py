@@ -526,3 +526,43 @@ def test_persistent_sweep_and_incremental_likelihood_equal_the_plain_form():
     assert {k: v for k, v in s0.items() if k != "launches"} == {k: v for k, v in s1.items() if k != "launches"}
     assert s0["acc_mh"] > 0 and s0["models"] > 25 * nch
     assert rt.load_library().rtmi_device_status() == 0
+
+
+@pytest.mark.gpu
+def test_sampler_sums_are_exact_hence_independent_of_the_launch_geometry():
+    """The sampler's sums of squared residuals are accumulated exactly (Acc192, csrc/rtmi_device.hpp), so the logL of a
+    model must not change by one bit when the launch geometry changes -- waves per workgroup, workgroups per chain (more
+    chains in the handle), scheduling knobs -- although different lanes, waves and workgroups then add up different sources."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod, synthetic as S
+    n = 20_000
+    off, dep = S.sampler_sources(n, 12)
+    rt.load_library(); rt.init(0)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"] + np.random.default_rng(4).normal(0, 0.016, n)
+    rt.set_sources(off, dep, obs)
+    nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    nodes2 = nodes.copy(); nodes2[3:, 1] *= 1.07
+    ref = None
+    defaults = {"waves_per_simd": 4, "refill_min": 32, "tail_group": 128, "retire_max": 12, "promote_age": 3}
+    try:
+        for knobs, nch in (({}, 8), ({"waves_per_simd": 2}, 8), ({"waves_per_simd": 3, "refill_min": 8}, 16),
+                           ({"tail_group": 0, "retire_max": 0, "promote_age": 0}, 32), ({"waves_per_simd": 1}, 64)):
+            for k, v in {**defaults, **knobs}.items():
+                rt.set_option(k, v)
+            h = raymod.NativeChains(nch, 11, n, T.Prior(), seed=1)
+            for i in range(nch):
+                h.set_chain(i, nodes if i % 2 == 0 else nodes2, 0.016, 1.0)
+            h.evaluate()
+            a = h.get_all()
+            got = (a["logL"][0], a["ss"][0], a["logL"][1], a["ss"][1])
+            assert np.all(a["logL"][0::2] == got[0]) and np.all(a["logL"][1::2] == got[2])
+            ref = ref or got
+            assert got == ref, (knobs, nch, got, ref)
+            del h
+    finally:
+        for k, v in defaults.items():
+            rt.set_option(k, v)
+    from oracle import oracle as O
+    v, d = T.layering(nodes)
+    want = O.oracle_loglhood_rt(obs, O.oracle_dff(v, d, off, dep), 0.016, stable=True)
+    assert abs(ref[0] - want) <= 1e-11 * abs(want)
