@@ -841,54 +841,59 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     HIP_TRY(hipSetDevice(h->device));
     if (record_every > 0 && !h->d_s_count)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: record_every > 0 needs rtmi_pt_sample_buffer first");
-    // Undecided engine: sweeps 0..5 of the first long enough call are persistent (one warm, two timed) and per-slot (one
-    // warm, two timed); then ONE event synchronisation, and the persistent launch stays unless it took more than 1.08x the
-    // time per proposal slot (its fixed cost weighs more in these first, short sweeps; the case to catch is a GPU shared
-    // with other processes, where it is several times slower).  The chains do not depend on the engine (bit-identical),
-    // so the trial is ordinary work.
-    // The window opens at the first sweep with at least five node slots (sweeps of one or two node slots are too short
-    // to tell: the cooperative launch has the larger fixed cost) and six more sweeps to go.
-    const bool trial = h->engine < 0 && h->use_persistent && nsweeps >= 8;
+    // Undecided engine: a window of ten sweeps in the first long enough call -- persistent: one warm, then a block of four
+    // timed as a whole; per-slot launches: one warm (captures its graph), then a block of four -- ONE event
+    // synchronisation, and the persistent launch stays unless its block took more than 1.08x the time per proposal slot.
+    // Blocks, not single sweeps: an event right around a cooperative launch also times the hand-over between the
+    // stream's queue and the cooperative queue, which back-to-back launches do not pay (single-sweep timing chose the
+    // per-slot launches for config 4's share, where the persistent launch is 10 % faster).  The case to catch is a GPU
+    // shared with other processes, where the persistent kernel is several times slower.  The chains do not depend on the
+    // engine (bit-identical), so the trial is ordinary work.  The window opens once the sweeps have their full length (see
+    // below) and ten more sweeps are to go; a call too short for that leaves the question to the next call.
+    const bool trial = h->engine < 0 && h->use_persistent && nsweeps >= 12;
     int t0 = -1;  // first sweep of the window
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int trial_slots[4] = {1, 1, 1, 1};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int block_slots[2] = {0, 0};
     if (trial)
         for (auto &e : ev)
-            HIP_TRY(hipEventCreate(&e));  // (eight: two per timed sweep)
+            HIP_TRY(hipEventCreate(&e));
     struct EvGuard {
         hipEvent_t *e;
         ~EvGuard()
         {
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 4; ++i)
                 if (e[i])
                     (void)hipEventDestroy(e[i]);
         }
     } ev_guard{ev};
     for (int s = 0; s < nsweeps; ++s) {
         int rc;
-        if (trial && t0 < 0 && h->engine < 0 && nsweeps - s >= 6) {
+        if (trial && t0 < 0 && h->engine < 0 && nsweeps - s >= 10) {
+            // not before the sweeps have the length they keep: the bound of k that sizes a sweep grows by one per sweep
+            // up to kmax (it is only refreshed at a synchronisation), and a sweep of kmax node slots, many of them
+            // without a proposal for most chains, is what a long run consists of
             const int kmax = h->d.pr.kmax, ks_next = h->kbound + 1 < kmax ? h->kbound + 1 : kmax;
-            if (ks_next >= (kmax < 5 ? kmax : 5))
+            if (ks_next >= kmax)
                 t0 = s;
         }
-        if (t0 >= 0 && s - t0 < 6 && h->engine < 0) {
-            // window sweeps 0, 3: warm; 1, 2 -> timed pair 0, 1 (persistent); 4, 5 -> timed pair 2, 3 (per-slot launches)
-            const int u = s - t0;
-            const int t = u % 3 == 0 ? -1 : (u < 3 ? u - 1 : u - 2);
-            rc = sweep_once(h, u < 3 ? 1 : 0, t >= 0 ? ev[2 * t] : nullptr, t >= 0 ? ev[2 * t + 1] : nullptr,
-                            t >= 0 ? &trial_slots[t] : nullptr);
+        if (t0 >= 0 && s - t0 < 10 && h->engine < 0) {
+            const int u = s - t0, blk = u / 5, v = u % 5;  // v = 0: warm; 1..4: the timed block
+            int slots = 0;
+            rc = sweep_once(h, blk == 0 ? 1 : 0, v == 1 ? ev[2 * blk] : nullptr, v == 4 ? ev[2 * blk + 1] : nullptr, &slots);
+            if (v >= 1)
+                block_slots[blk] += slots;
         } else {
             rc = sweep_once(h, h->engine == 1 ? 1 : 0);
         }
         if (rc)
             return rc;
-        if (t0 >= 0 && s - t0 == 5 && h->engine < 0) {
-            float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            HIP_TRY(hipEventSynchronize(ev[7]));
-            for (int t = 0; t < 4; ++t)
-                HIP_TRY(hipEventElapsedTime(&ms[t], ev[2 * t], ev[2 * t + 1]));
-            const float per_p = (ms[0] + ms[1]) / (float)(trial_slots[0] + trial_slots[1]);
-            const float per_g = (ms[2] + ms[3]) / (float)(trial_slots[2] + trial_slots[3]);
+        if (t0 >= 0 && s - t0 == 9 && h->engine < 0) {
+            float ms_p = 0.0f, ms_g = 0.0f;
+            HIP_TRY(hipEventSynchronize(ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms_p, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms_g, ev[2], ev[3]));
+            const float per_p = ms_p / (float)(block_slots[0] > 0 ? block_slots[0] : 1);
+            const float per_g = ms_g / (float)(block_slots[1] > 0 ? block_slots[1] : 1);
             h->engine = per_p <= 1.08f * per_g ? 1 : 0;
             if (getenv("RTMI_PT_VERBOSE"))
                 fprintf(stderr, "rtmi: sweep engines timed: persistent %.1f us per slot, per-slot launches %.1f us per slot -> %s\n",
