@@ -1108,10 +1108,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArg
         chain = blockIdx.x / gx;
         row = blockIdx.x % gx;
     }
-    const int S = 2 * w.nslots_k;  // slots with an evaluation: birth/death, then (node 0, v), (node 1, z), (node 1, v), ...
+    // Slots with an evaluation: birth/death, then (node 0, v), (node 1, z), (node 1, v), ...  The host sizes the sweep for
+    // the largest k any chain can have by now (a bound); a chain's own k is final once its birth/death slot is decided (the
+    // step of slot 1), and the slots of nodes it does not have propose nothing -- the chain leaves them out (S_c below).
+    int S_c = 2 * w.nslots_k;
     volatile unsigned int *flag = w.flag + chain, *count = w.count + chain, *abort_word = w.abort_;
+    // arrivals are counted from where the word stands at the start of this launch (the previous launch has finished)
+    const unsigned int count_base = __hip_atomic_load((unsigned int *)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 1
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < S_c; ++s) {
         const int decide = s == 0 ? (int)PT_NONE : (s == 1 ? (int)PT_BD : (int)PT_MH);
         const int propose = s == 0 ? (int)PT_BD : (int)PT_MH;
         const unsigned int target = w.epoch + (unsigned int)s + 1u;
@@ -1132,13 +1137,18 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArg
                 return;
             __builtin_amdgcn_s_dcache_inv();
         }
+        if (s == 1) {
+            // k of this chain for the rest of the sweep (written by the step that has just run, visible after the hand-shake)
+            const int kc = __builtin_amdgcn_readfirstlane(dp->k[chain]);
+            S_c = 2 * kc < S_c ? 2 * kc : S_c;
+        }
         fused_body<double, false, false, true, false, ROWS, INCR>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
         __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
         if (threadIdx.x == 0) {
             __threadfence();
             __hip_atomic_fetch_add((unsigned int *)count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             if (row == 0)
-                go_on = pt_wait_reached(count, target * (unsigned int)gx, abort_word, d_status) ? 1 : 0;
+                go_on = pt_wait_reached(count, count_base + (unsigned int)(s + 1) * (unsigned int)gx, abort_word, d_status) ? 1 : 0;
         }
         if (row == 0) {
             __syncthreads();
