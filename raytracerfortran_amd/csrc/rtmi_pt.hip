@@ -511,6 +511,18 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.partial_x = h->d_partial_x;
         d.inc = h->d_inc;
         d.cache_valid = h->d_cache_valid;
+        d.incremental = (h->incremental && h->d_partial_x) ? 1 : 0;  // (exact sums: the fused kernel path)
+        {
+            // the deepest source (once, on the host): proposals that change the model only below it need no launch
+            std::vector<double> dep(n);
+            ok = ok && hipStreamSynchronize(h->stream) == hipSuccess &&
+                 hipMemcpy(dep.data(), h->d_set + n, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+            double zm = -INFINITY;
+            for (double z : dep)
+                if (z == z && z > zm)
+                    zm = z;
+            d.zmax_src = zm;
+        }
         // every chain starts as a half-space at the middle of the velocity prior, sigma 0.01, beta 1 (as the host
         // engine of round 1 did); rtmi_pt_set_chain overrides
         std::vector<double> init(nc * K, 0.0), sd0(nc, 0.01), b0(nc, 1.0);

@@ -29,7 +29,8 @@ struct PtDev {
     double *sd, *logL, *ss, *beta;
     unsigned long long *ctr;
     // proposal of the current slot
-    int *pk, *pactive;    // pactive: 0 none, 1 proposal awaiting its decision, 2 evaluation of the current state
+    int *pk, *pactive;    // pactive: 0 none, 1 proposal awaiting its decision, 2 evaluation of the current state,
+                          // 3 proposal that changes the model only below every source: its SS is the current one, nothing was launched
     double *pz, *pv, *plp;
     // batch rows of the likelihood launch and its per-workgroup residual sums
     double *V, *D;        // [nchains][ld_model]
@@ -40,6 +41,8 @@ struct PtDev {
     // incremental likelihood (rtmi_kernels.h::PtInc): what the step tells the likelihood about each chain's proposal
     rtmi::PtInc *inc;     // [nchains]
     int *cache_valid;     // [nchains] r2cur holds the residuals of the chain's current model (cleared by rtmi_pt_set_chain)
+    double zmax_src;      // the deepest source of the handle's set
+    int incremental;      // the incremental likelihood is on (RTMI_PT_INCREMENTAL)
 };
 
 #define PT_STEP_THREADS 256
@@ -81,7 +84,9 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     const rtmi::PtInc ic = d.inc[c];  // of the proposal that has just been evaluated (if any)
     int cache_ok = d.cache_valid[c];
     double part = 0.0;  // SUM(DresRT**2) over the workgroups' sums
-    if (decide != PT_NONE && act != 0) {
+    if (decide != PT_NONE && act == 3) {
+        part = ss;  // no source is affected: every residual, hence the (exact) sum, is the current model's
+    } else if (decide != PT_NONE && act != 0) {
         if (d.partial_x) {  // exact: any order gives the same words
             rtmi::Acc192 tot = rtmi::acc_zero();
             for (int j = 0; j < d.gx; ++j) {
@@ -132,8 +137,9 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 took = true;
             }
         }
-        if (lead) {
+        if (lead)
             d.pactive[c] = 0;
+        if (lead && act != 3) {  // (act == 3: nothing was launched, nothing moved, no residuals of its own)
             // The launch that evaluated this model has moved the residuals of an earlier accepted proposal to r2cur.  If
             // this one is taken, ITS residuals (in r2prop, for the sources it affected) are the pending ones now; a model
             // that was evaluated in full makes the cache valid.
@@ -147,7 +153,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                     d.cache_valid[c] = 1;
             }
         }
-        if (took && ic.zthr == -INFINITY)
+        if (took && act != 3 && ic.zthr == -INFINITY)
             cache_ok = 1;
     }
 
@@ -288,6 +294,10 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     const double dl_all = group_max((in && i >= 1) ? zi : -INFINITY);
     const double dl_new = qk == 1 ? 9999.9 : dl_all;
     const bool ok = have && (__ballot(bad) & gmask) == 0ull;
+    // A proposal that changes the model only below the deepest source (and leaves both models' last interfaces below it:
+    // whichLayer's special case) affects no source: its sum of squared residuals IS the current one, bit for bit (the sums
+    // are exact), and no likelihood is launched for it -- about a third of the prior's nodes lie below the data.
+    const bool trivial = d.incremental && cache_ok && zthr > d.zmax_src && dl_cur > d.zmax_src && dl_new > d.zmax_src;
     int nl = 0;
     if (ok) {
         // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision
@@ -313,13 +323,17 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
         if (lead) {
             d.pk[c] = qk;
             d.plp[c] = lp;
-            d.pactive[c] = 1;
+            d.pactive[c] = trivial ? 3 : 1;
             st[6] += 1;  // a model that goes through the likelihood
-            rtmi::PtInc *o = d.inc + c;
-            o->zthr = zthr;
-            o->dl1 = dl_cur;
-            o->dl2 = dl_new;
+            if (!trivial) {
+                rtmi::PtInc *o = d.inc + c;
+                o->zthr = zthr;
+                o->dl1 = dl_cur;
+                o->dl2 = dl_new;
+            }
         }
+        if (trivial)
+            nl = 0;  // an inactive row: the workgroups of this chain have nothing to do in this slot
     } else if (have && lead) {
         st[2 * propose + 1] += 1;  // proposed, rejected outside the prior (:707-711)
     }
