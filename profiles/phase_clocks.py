@@ -5,6 +5,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracerfortran_amd as rt
+from raytracerfortran_amd import raymod
+if os.environ.get("RTMI_AB_LIB"):  # another build of the library (A/B of the phase clocks on one box)
+    raymod.LIB_PATH = os.path.abspath(os.environ["RTMI_AB_LIB"])
 import bench
 lib = rt.load_library(); rt.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

@@ -29,6 +29,9 @@ enum : int {
 #ifndef RTMI_TERM_GROUP
 #define RTMI_TERM_GROUP 3  // layer terms evaluated side by side in eval_terms' main loop
 #endif
+#ifndef RTMI_PREDICT
+#define RTMI_PREDICT 1  // 0: every evaluation of solve() is made (A/B builds; see newton_lands_converged)
+#endif
 #define RTMI_TABLE_STRIDE(nlayers) ((nlayers) + 2)
 // Models of up to RTMI_ROWS_MAX_NL interfaces also get the pair table once per stack height ("rows", see LayerTable);
 // `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
@@ -181,6 +184,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         int jm = 0;           // first layer that carries the maximum (for the scheduling hint below)
         bool okrun = true;    // H, H*V of layers 0..i are 0 or of moderate magnitude and V of moderate magnitude
         bool sorted = true;   // interfaces in non-decreasing order (no NaN): which_layer may search by bisection
+        bool posv = true;     // every velocity > 0 (no NaN): with sorted interfaces and D[0] >= 0 no term of f, f' is negative
         for (int base = 0; base <= nlayers; base += 64) {
             const int i = base + lane;
             const bool in = i <= nlayers, inl = i < nlayers;
@@ -215,6 +219,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
             const bool hvok_l = okrun && lane < firstbad;
             okrun = okrun && bad == 0ull;
             sorted = sorted && __ballot(!so_l) == 0ull;
+            posv = posv && __ballot(in && !(v > T(0.0))) == 0ull;
             if (in) {
                 t.VMAX[i] = vmax_l;
                 t.Q[i] = (T)jm_l;  // Q[i] has served: it now holds the index of the fastest layer of the stack 0..i
@@ -225,8 +230,8 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
                 t.HVOK[i] = hvok_l ? T(1.0) : T(0.0);
             }
         }
-        if (lane == 0)
-            t.HVOK[nlayers] = (sorted && t.D[0] == t.D[0]) ? T(1.0) : T(0.0);  // spare entry: the "sorted" flag
+        if (lane == 0)  // spare entry: 0 = unsorted interfaces, 1 = sorted, 2 = sorted, no negative thickness, every velocity positive
+            t.HVOK[nlayers] = (sorted && t.D[0] == t.D[0]) ? ((posv && t.D[0] >= T(0.0)) ? T(2.0) : T(1.0)) : T(0.0);
     }
     __syncthreads();
     if (t.HWR) {
@@ -249,7 +254,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         // only orders the work, no result depends on it.
         // The table costs O(nlayers^2) operations per workgroup (approximate single-precision reciprocal and
         // reciprocal square root: a few instructions per pair of layers).
-        const bool hint_unused = t.SA != nullptr;  // see trip_class
+        const bool hint_unused = false;  // models with the bound of bisection_skip use it for their longest sources only (trip_class)
         for (int il = 1 + (int)threadIdx.x; il <= nlayers && !hint_unused; il += blockDim.x) {
             if (nlayers > RTMI_HINT_MAX_NL) {
                 // very deep models: one class for all bisection sources (measured at 1024 interfaces: ordering by
@@ -335,12 +340,14 @@ __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T
     // Models that carry the bound of bisection_skip (<= RTMI_SKIP_MAX_NL interfaces) enter the
     // bisection a trip or two before it ends, whatever the geometry: one class (measured: -9 % on a tempering slot
     // against the three classes below, which sort by the trips that are no longer made).
-    if (t.SA)
-        return RTMI_TRIP_CLASSES - 1;
     const T hl = z - t.D[il - 1];
     const T num = R - (t.PA[il] + hl * t.PC[il]);
     const T hj = t.PH[il];
     const T den = hj > T(0.0) ? hj : hl;
+    // ... except the rays so close to critical that the bisection runs to its last trips and the Newton iteration after it
+    // creeps (8 evaluations on average, up to 17, against 3): those go first, so that they are finished before the queue runs dry
+    if (t.SA)
+        return num > den * T(128.0) ? 0 : RTMI_TRIP_CLASSES - 1;
     int c = RTMI_TRIP_CLASSES - 1;
     c -= (num > den * T(9.51));    // 2^3.25: about 12 evaluations or more
     c -= (num > den * T(64.0));    // 2^6:    about 17.5 or more
@@ -889,6 +896,7 @@ struct Lane {
     bool conv;
     bool numer_ok;  // hvl and the table products of the stack are inside eval_f_fp's fast-path guard
     bool skip0;     // solvebst's first evaluation, f(x1 = 1d-10) (:354), is provably positive: only its sign is used
+    bool pred_ok;   // the stack and the source are inside the guards of newton_lands_converged
 };
 
 // The source's layer-dependent constants (InsertLayer :38-69 as table lookups).  il = nl - 1 >= 1.
@@ -911,6 +919,47 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
     // (a 1 % margin over all of that) proves f1 > 0 whatever the last bits are, and the evaluation -- one whole trip
     // of the source, for two sources in three -- need not be made.  NaN or Inf anywhere makes the test false.
     s.skip0 = s.R > T(1.01e-10) * (t.PSA[il - 1] + fabs(s.hvl)) && t.VMAX[il] < T(1e7);
+    // guards of newton_lands_converged: f and f' are sums of non-negative terms (sorted interfaces from a non-negative
+    // depth, positive velocities, the source not above its layer's top), everything of moderate magnitude
+    s.pred_ok = std::is_same<T, double>::value && s.numer_ok && t.HVOK[t.nul - 1] == T(2.0) && hl >= T(0.0) &&
+                s.R < T(1e5) && t.VMAX[il] < T(1e7);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The evaluation that need not be made: solve()'s LAST one (:281-291), which only confirms abs(fx) < tol.
+//
+// Model of the arithmetic: F(p) = R - sum_i hv_i p / sqrt(1 - p^2 vv_i) with the table's (rounded) hv_i >= 0, vv_i as exact
+// coefficients; the solver's fx, fxprime at x are F(x) + e1 and F'(x) (1 + e2).  F is decreasing and CONCAVE on
+// (0, 1/vmax):  F'' = -sum 3 hv_i vv_i p / s_i^5.  A Newton step taken where fx < 0 moves left, xnew = x - fx/fxprime < x,
+// and Taylor at x gives
+//     F(xnew) = [F(x) + F'(x) (xnew - x)] + F''(xi) (xnew - x)^2 / 2,      xi in [xnew, x].
+// |F''| grows with p, and vv_i / w_i(x) <= vmax^2 / w_min(x) with w_min = 1 - x^2 vmax^2, so on that interval
+//     |F''(xi)| <= 3 x (vmax^2 / w_min) sum hv_i / s_i(x)^3 = 3 x (vmax^2 / w_min) |F'(x)|,
+// and with |F'(x)| q^2 = |fx q| (q = fx/fxprime) the quadratic term is at most  B = 1.5 x vmax^2 |fx q| / w_min.
+// The bracket is what the Newton step cancels; what is left of it are the roundings:
+//     |bracket| <= |F(x)| (|e2| + 2^-53) + |e1| + |F'(x)| ulp(x)/2.
+// Under the guards below (R < 1e5, every w_i >= w_min > 1e-8, |fx| < 1e4, |q| > 1e-9 x, <= 1025 layers) a term of the sums
+// carries a relative error below 2.3e-16 / (2 w) + 5 ulp < 1.2e-8 (3.5e-8 in f'), hence |e1| < 1.4e-3, |e2| < 4e-8, the
+// bracket < 2.9e-3, and the value the solver would COMPUTE at xnew differs from F(xnew) by < 1.2e-3.  B <= 0.08 therefore
+// proves abs(costFunc(xnew)) < 0.0842 < tol: the next trip of solve's loop would set conv = .TRUE. and leave with x = xnew
+// (:287-291) -- provided it is a trip of the loop (this one is not the 15th) and xnew was not clamped (:299-304).
+// The bound decides only WHETHER that evaluation is made, never a value.  NaN anywhere makes it false.  Double precision
+// only: in single precision the noise of the sums is of the order of tol.  On the C2 stream this is the last evaluation
+// of 92 % of the sources: 3.85 -> 2.94 evaluations per source in the solve loop (profiles/sim_predict.py).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool newton_lands_converged(const LayerTable<T> &t, const Lane<T> &s, T x, T f, T q, T xnew)
+{
+    if constexpr (!std::is_same<T, double>::value || !RTMI_PREDICT) {
+        return false;
+    } else {
+        const T vmax = t.VMAX[s.nfull];
+        const T y = x * vmax;
+        const T w = T(1.0) - y * y;
+        const T b = T(1.5) * (y * vmax) * fabs(f * q);
+        return s.pred_ok && f < T(0.0) && xnew < x && xnew > T(0.0) && w > T(1e-8) && b <= T(0.08) * w && f > T(-1e4) &&
+               fabs(q) > T(1e-9) * x;
+    }
 }
 
 // The state after solvebst's entry (:354-365) and its first `dx = dx*0.5; xmid = x + dx` (:368-369), given the sign of
@@ -1022,7 +1071,7 @@ __device__ __forceinline__ void lane_start(Lane<T> &s, T p0)
 // the fused kernel evaluates ST_INIT in a pass of its own and never meets it in the solve loop.
 enum : int { ADV_ANY = 0, ADV_INIT_ONLY = 1, ADV_NO_INIT = 2 };
 template <int MODE = ADV_ANY, typename T>
-__device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
+__device__ __forceinline__ void lane_advance(const LayerTable<T> &t, Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
     const bool isI = MODE == ADV_INIT_ONLY ? true : (MODE == ADV_NO_INIT ? false : st == ST_INIT);
@@ -1057,6 +1106,8 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     const bool n_conv = newt && small;
     const bool n_go = newt && !small;
     T xnew = xN - q;                // x = x - deltax (:298)
+    // the next trip of solve's loop would only confirm convergence at xnew (newton_lands_converged): it is not made
+    const bool n_pred = n_go && kN != 15 && newton_lands_converged(t, s, xN, f, q, xnew);
     if (xnew > s.vmi)
         xnew = s.clampv;                    // (:299-304)
 
@@ -1077,11 +1128,11 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
     s.x = n_go ? xnew : (n_conv ? xN : (bis_done ? xb2 : s.x));
     s.xe = initB ? T(1e-10) : (halve ? xmid : (bis_done ? xb2 : (n_go ? xnew : s.xe)));
     s.k = isB0 ? 1 : (bis_cont ? s.k + 1 : (bis_done ? 1 : ((n_go && kN != 15) ? kN + 1 : (initN ? 1 : s.k))));
-    s.conv = n_conv ? true : (isF ? (fabs(f) > T(0.1)) : s.conv);  // (:288) | the inverted test (:327-330)
+    s.conv = (n_conv || n_pred) ? true : (isF ? (fabs(f) > T(0.1)) : s.conv);  // (:288) | the inverted test (:327-330)
     s.st = initB ? ST_BIS0
                  : (isB0 || bis_cont) ? ST_BIS
                                       : bis_done ? ST_NEWTON
-                                                 : n_go ? (kN == 15 ? ST_FINAL : ST_NEWTON)
+                                                 : n_go ? (n_pred ? ST_DONE : (kN == 15 ? ST_FINAL : ST_NEWTON))
                                                         : (n_conv || isF) ? ST_DONE : st;
     if constexpr (MODE == ADV_ANY) {
         if (initB && s.skip0)  // f(x1) is provably positive: straight to the first midpoint (see lane_setup)
@@ -1094,12 +1145,14 @@ __device__ __forceinline__ void lane_advance(Lane<T> &s, T f, T fp)
                 s.st = ST_DONE;
             } else {
                 T xn = xb2 - q;
+                const bool pred = newton_lands_converged(t, s, xb2, f, q, xn);
                 if (xn > s.vmi)
                     xn = s.clampv;
                 s.x = xn;
                 s.xe = xn;
                 s.k = 2;
-                s.st = ST_NEWTON;
+                s.st = pred ? ST_DONE : ST_NEWTON;
+                s.conv = pred ? true : s.conv;
             }
         }
     }
@@ -1210,7 +1263,7 @@ __device__ __forceinline__ void lane_skip_idle_trips(const LayerTable<T> &t, Lan
 // lane_advance for a lane in ST_INIT (the fused kernel's first-evaluation pass): GetPTime's branch (:136-153) after
 // cf = f(p0), cfp = f'(p0).  Same operations on the same operands as lane_advance.
 template <typename T>
-__device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp, bool live)
+__device__ __forceinline__ void lane_advance_init(const LayerTable<T> &t, Lane<T> &s, T f, T fp, bool live)
 {
     const T q = solver_quotient(f, fp, live);  // cf/cfp (:138)
     const bool neg = f < T(0.0);
@@ -1218,10 +1271,11 @@ __device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp, bool li
     const T check_x = s.xe - q;                // check_x = p0 - cf/cfp (:138)
     const bool newton = neg || check_x < s.safe;  // (:139-144) Newton straight from p0, else bisection first (:145-148)
     T xnew = s.xe - q;                         // solve's first trip: x = p0 - deltax (:298)
+    const bool go = newton && !small;
+    const bool pred = go && newton_lands_converged(t, s, s.xe, f, q, xnew);  // the second trip would only confirm convergence
     if (xnew > s.vmi)
         xnew = s.clampv;                       // (:299-304)
-    const bool conv = newton && small;
-    const bool go = newton && !small;
+    const bool conv = (newton && small) || pred;
     s.x = go ? xnew : s.x;                     // converged at p0: x stays p0
     s.xe = go ? xnew : (newton ? s.xe : T(1e-10));
     s.k = go ? 2 : (newton ? 1 : s.k);
@@ -1234,7 +1288,7 @@ __device__ __forceinline__ void lane_advance_init(Lane<T> &s, T f, T fp, bool li
 // are mostly in the same phase of their solves, so most trips execute one block; inside a block the updates are
 // plain masked writes instead of chains of selects.  Same operations on the same operands as lane_advance.
 template <typename T>
-__device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
+__device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<T> &s, T f, T fp)
 {
     const int st = s.st;
     const T q = solver_quotient(f, fp, st != ST_DONE);  // deltax of solvebst (:384) and of solve (:294)
@@ -1254,9 +1308,11 @@ __device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
         // evaluation less for nearly every bisection source.
         const bool fuse = done && (neg || (!zero && jump));
         T xnew = s.xe - q;                   // x = x - deltax (:298)
+        // ... and solve's SECOND trip is not made when it would only confirm convergence (newton_lands_converged)
+        const bool pred = fuse && !small && newton_lands_converged(t, s, s.xe, f, q, xnew);
         if (xnew > s.vmi)
             xnew = s.clampv;                 // (:299-304)
-        const bool f_conv = fuse && small, f_go = fuse && !small;
+        const bool f_conv = (fuse && small) || pred, f_go = fuse && !small;
         s.xb = xb2;
         s.dx = done ? s.dx : dxh;
         s.xe = f_go ? xnew : (done ? xb2 : xb2 + dxh);
@@ -1266,14 +1322,16 @@ __device__ __forceinline__ void lane_advance_solve(Lane<T> &s, T f, T fp)
         s.st = f_conv ? ST_DONE : (done ? ST_NEWTON : ST_BIS);
     } else if (st == ST_NEWTON) {
         T xnew = s.x - q;                    // x = x - deltax (:298)
+        const bool last = (s.k == 15);
+        // the next trip would only confirm convergence at xnew (newton_lands_converged): the source is finished now
+        const bool pred = !small && !last && newton_lands_converged(t, s, s.x, f, q, xnew);
         if (xnew > s.vmi)
             xnew = s.clampv;                 // (:299-304)
-        const bool last = (s.k == 15);
-        s.conv = small ? true : s.conv;      // (:288)
+        s.conv = (small || pred) ? true : s.conv;  // (:288)
         s.x = small ? s.x : xnew;
         s.xe = small ? s.xe : xnew;
         s.k = (small || last) ? s.k : s.k + 1;
-        s.st = small ? ST_DONE : (last ? ST_FINAL : ST_NEWTON);
+        s.st = (small || pred) ? ST_DONE : (last ? ST_FINAL : ST_NEWTON);
     } else if (st == ST_FINAL) {
         s.conv = fabs(f) > T(0.1);           // the inverted test (:327-330)
         s.st = ST_DONE;

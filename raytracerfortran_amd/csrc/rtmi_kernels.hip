@@ -84,7 +84,7 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
         T f, fp;
         eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, s.st != ST_DONE, f, fp);
         const bool was_init = s.st == ST_INIT;
-        lane_advance(s, f, fp);
+        lane_advance(t, s, f, fp);
         if (was_init && s.skip0 && s.st == ST_BIS)  // solvebst entered with f(x1) > 0: idle trips need not be made
             lane_skip_idle_trips(t, s, il, z - t.D[il - 1]);
     }
@@ -207,6 +207,10 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
     return nl_max <= 63 ? nl : (int)(((long long)nl * 63) / nl_max);
 }
 
+#ifndef RTMI_ENGINE
+#define RTMI_ENGINE 0        // solve phase of the fused kernel: 1 = per-wave passes over sorted records, 0 = workgroup queue with lane refill
+#endif
+#define RTMI_STRAGGLERS 24   // (passes) a wave with fewer unfinished sources than this after a pass hands them to the finishers
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..23 (nl <= 1025)
 #define RTMI_RK_NL_MASK 0x7FFu
@@ -454,6 +458,255 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             stamps[5] = clock64();  // records in their slots, p0 computed
         const int nq = __builtin_amdgcn_readfirstlane((int)qctl[1]);  // wave-uniform values are kept in SGPRs
 
+        if constexpr (RTMI_ENGINE == 1) {
+        // ---- P. the solve as per-wave PASSES over sorted records (no queue, no hand-overs, no barriers) ------------
+        // With the evaluations that need not be made gone (bisection_skip, the fused first iterations, the predicted
+        // last one: newton_lands_converged) a source takes 2.9 evaluations after its first, nearly all sources 2 ... 4.
+        // So every wave keeps to ITS OWN chunks of the sorted records (chunk c = slots 64 c ..., one layer count) from
+        // here to the travel times:
+        //   pass 0    evaluate at p0 -- GetPTime's branch (:136-153), solve's first trip or solvebst's entry with the
+        //             idle trips skipped -- park the solver state in the record (rp = x or the bracket end, tnl = state
+        //             word; dx is +-(x2 - x1) 2^-k exactly) and list the unfinished records, in slot order;
+        //   pass n    walk that list 64 records at a time (still sorted by layer count: one trip count per wave and no
+        //             padded terms), evaluate, advance, park, compact the list in place;
+        //   the last few sources of a wave (fewer than RTMI_STRAGGLERS left after a pass) go to a list of the
+        //             workgroup; the last waves to arrive there finish them, lanes keeping their source to the end;
+        //   travel times of the wave's own chunks (the finished records; the stragglers' by whoever finished them).
+        // Waves never wait for each other before the end of the round (the finishers wait for the last arrivals only).
+        typedef __attribute__((address_space(3))) uint32_t lds_u32p;
+        volatile lds_u32p *sctl = (volatile lds_u32p *)(hist + 512);     // [0] stragglers listed, [1] waves arrived
+        uint16_t *slist = reinterpret_cast<uint16_t *>(hist);            // <= 16 x (RTMI_STRAGGLERS - 1) slots
+        const int nchq = (nq + 63) >> 6;
+        if (threadIdx.x == 0) {
+            sctl[0] = 0;
+            sctl[1] = 0;
+        }
+        // hist (the sort's slot table) is free once every wave has placed its records: that was the barrier above; the
+        // two control words are first touched after at least one pass, i.e. after thread 0's stores (same wave: program
+        // order; other waves: they arrive after their passes -- and the finishers re-read under a fence)
+        __syncthreads();
+        const int qd = nchq / nwib, rm = nchq % nwib;
+        uint16_t *mylist = order + 64 * (wib * qd + (wib < rm ? wib : rm));  // this wave's chunks, as many slots
+        int nlist = 0;
+        unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0;
+        auto diag_trip = [&](bool busy, int nfw, int nfull) {
+            if (DIAG && fine) {
+                ++dg_iters;
+                dg_busy += (unsigned long long)__popcll(__ballot(busy));
+                dg_trips += (unsigned long long)(nfw + 1);
+                int terms = busy ? nfull + 1 : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    terms += __shfl_xor(terms, off, 64);
+                dg_terms += (unsigned long long)terms;
+            }
+        };
+        // park the state of an unfinished source / publish a finished one
+        auto park = [&](int q, uint32_t key, const Lane<T> &s) {
+            if (s.st == ST_DONE) {
+                rp[q] = s.x;
+                rk[q] = key | (s.conv ? (RTMI_RK_DONE | RTMI_RK_CONV) : RTMI_RK_DONE);
+            } else {
+                rp[q] = (s.st == ST_BIS) ? s.xb : s.x;  // BIS0: unused (xe = 1d-10)
+                tnl[q] = (uint32_t)s.st | ((uint32_t)s.k << 8) | (s.dx > T(0.0) ? 1u << 16 : 0u) | (s.conv ? 1u << 17 : 0u);
+            }
+        };
+        // the solver state of record q back in a lane
+        auto unpark = [&](int q, bool valid, Lane<T> &s) -> uint32_t {
+            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
+            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
+            const uint32_t sw = valid ? tnl[q] : (uint32_t)ST_DONE;
+            const T xv = valid ? rp[q] : T(0.0);
+            s.st = (int)(sw & 0xFFu);
+            s.k = (int)((sw >> 8) & 0xFFu);
+            s.conv = ((sw >> 17) & 1u) != 0u;
+            const T e2 = s.vmi - T(1e-12), e21 = e2 - T(1e-10);   // as lane_enter_bisection
+            const T dxb = ldexp((sw >> 16) & 1u ? e21 : -e21, -s.k);  // halvings are exact
+            const bool bis = s.st == ST_BIS;
+            s.xb = bis ? xv : T(0.0);
+            s.dx = bis ? dxb : T(0.0);
+            s.x = xv;
+            s.xe = bis ? xv + dxb : (s.st == ST_BIS0 ? T(1e-10) : xv);
+            return key;
+        };
+        // ---- pass 0: first evaluation of the wave's chunks
+        for (int c = wib; c < nchq; c += nwib) {
+            const int q = c * 64 + lane;
+            const bool valid = q < nq;
+            Lane<T> s;
+            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
+            const T p0 = valid ? rp[q] : T(0.0);
+            const T zq = valid ? rz[q] : T(1.0);
+            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), zq);
+            lane_start(s, p0);
+            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
+            if (!live)
+                s.st = ST_DONE;
+            const int nfw = wave_max_i32(live ? s.nfull : 0);
+            diag_trip(live, nfw, s.nfull);
+            T f, fp;
+            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
+            {
+                const Lane<T> keep = s;  // every lane takes part (wave-uniform choice of the divide); dead lanes are restored
+                lane_advance_init(t, s, f, fp, live);
+                if (!live)
+                    s = keep;
+            }
+            if (live && s.st == ST_BIS0 && s.skip0) {
+                lane_enter_bisection(s, false);  // f(1e-10) > 0 without evaluating it (lane_setup)
+                lane_skip_idle_trips(t, s, nl - 1, zq - t.D[nl - 2]);
+            }
+            const bool todo = valid && s.st != ST_DONE;
+            if (valid)
+                park(q, key, s);
+            const unsigned long long tb = __ballot(todo);
+            if (todo)
+                mylist[nlist + __popcll(tb & lt_mask)] = (uint16_t)q;
+            nlist += __popcll(tb);
+        }
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[6] = stamps[1] = clock64();  // first evaluation done (wave 0)
+        // ---- passes 1, 2, ...
+        int pass = 0;
+#pragma unroll 1
+        while (nlist > 0) {
+            if (nlist < RTMI_STRAGGLERS && pass >= 1)
+                break;
+            ++pass;
+            int wr = 0;
+#pragma unroll 1
+            for (int r = 0; r < nlist; r += 64) {
+                const bool valid = r + lane < nlist;
+                const int q = valid ? (int)mylist[r + lane] : 0;
+                Lane<T> s;
+                const uint32_t key = unpark(q, valid, s);
+                const int nfw = wave_max_i32(valid ? s.nfull : 0);
+                diag_trip(valid, nfw, s.nfull);
+                T f, fp;
+                eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, valid, f, fp);
+                lane_advance_solve(t, s, f, fp);
+                const bool todo = valid && s.st != ST_DONE;
+                if (valid)
+                    park(q, key, s);
+                const unsigned long long tb = __ballot(todo);
+                if (todo)
+                    mylist[wr + __popcll(tb & lt_mask)] = (uint16_t)q;  // wr <= r: the list is compacted in place
+                wr += __popcll(tb);
+            }
+            nlist = wr;
+        }
+        if (DIAG && stamps && j0 == 0 && lane == 0)
+            stamps[8 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave's passes are over
+        // ---- the wave's last sources go to the workgroup's list; the last NF waves to arrive finish them
+        int arrival = 0, sbase = 0;
+        if (lane == 0) {
+            if (nlist > 0)
+                sbase = (int)atomicAdd(hist + 512, (uint32_t)nlist);
+        }
+        sbase = __builtin_amdgcn_readfirstlane(sbase);
+        if (lane < nlist) {  // nlist < RTMI_STRAGGLERS <= 64
+            const uint16_t q = mylist[lane];
+            slist[sbase + lane] = q;
+            tnl[q] |= 0x80000000u;  // handed over: its travel time is the finisher's business
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            arrival = (int)atomicAdd(hist + 513, 1u);
+        arrival = __builtin_amdgcn_readfirstlane(arrival);
+        const int NF = nwib < 4 ? nwib : 4;
+        const int fin = arrival - (nwib - NF);  // >= 0: this wave is finisher number `fin`
+        if (fin >= 0) {
+            int polls = 0;
+#pragma unroll 1
+            while ((int)sctl[1] < nwib) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1 << 24)) {  // never expected: every wave arrives
+                    if (a.d_status && lane == 0)
+                        atomicOr(a.d_status, 4);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int total = (int)sctl[0];
+#pragma unroll 1
+            for (int g = fin * 64; g < total; g += NF * 64) {
+                const bool valid = g + lane < total;
+                const int q = valid ? (int)slist[g + lane] : 0;
+                Lane<T> s;
+                const uint32_t key = unpark(q, valid, s);
+#pragma unroll 1
+                while (__any(s.st != ST_DONE)) {
+                    const bool busy = s.st != ST_DONE;
+                    const int nfw = wave_max_i32(busy ? s.nfull : 0);
+                    diag_trip(busy, nfw, s.nfull);
+                    T f, fp;
+                    eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, busy, f, fp);
+                    lane_advance_solve(t, s, f, fp);
+                }
+                if (valid)
+                    park(q, key, s);
+            }
+        }
+        if (DIAG && stamps && j0 == 0 && lane == 0) {
+            stamps[9 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave's last source finished
+            stamps[10 + RTMI_STAMPS_PER_WAVE * wib] = dg_iters;
+            stamps[11 + RTMI_STAMPS_PER_WAVE * wib] = dg_busy;
+            stamps[12 + RTMI_STAMPS_PER_WAVE * wib] = dg_trips;
+            stamps[13 + RTMI_STAMPS_PER_WAVE * wib] = dg_terms;
+        }
+        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+            stamps[2] = clock64();
+        // ---- c. travel times of the wave's own chunks (the finished records), then of the stragglers it finished
+        auto time_of = [&](int q, bool valid) {
+            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
+            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
+            const T p = valid ? rp[q] : T(0.0);
+            const T z = valid ? rz[q] : T(1.0);
+            const int nfw = wave_max_i32(valid ? il : 0);
+            T tt = travel_time(t, p, il, nfw, il, z, valid);
+            if (!(key & RTMI_RK_CONV))
+                tt = -T(999.0);
+            if (valid) {
+                const int loc = (int)(key & RTMI_RK_LOC_MASK);
+                const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
+                if (WANT_T)
+                    a.d_timeP[k] = tt;
+                if (WANT_P)
+                    a.d_p_final[k] = p;
+                if (WANT_SS) {
+                    const T r = a.d_obs[k] - tt;
+                    if constexpr (INC) {
+                        acc_add_double(acc, (double)(r * r));
+                        if (inc)
+                            a.d_r2prop[k] = r * r;
+                    } else {
+                        rR[q] = r * r;  // the record's R is not needed any more
+                    }
+                }
+            }
+        };
+        // the stragglers of this wave's chunks are not DONE yet (or were finished by this very wave: they are in its
+        // groups below): the flag is read once, before the finisher part publishes anything for them
+        if (fin >= 0) {
+            // a finisher first deals with what only it can do ...
+            const int total = (int)sctl[0];
+#pragma unroll 1
+            for (int g = fin * 64; g < total; g += NF * 64) {
+                const bool valid = g + lane < total;
+                time_of(valid ? (int)slist[g + lane] : 0, valid);
+            }
+        }
+#pragma unroll 1
+        for (int c = wib; c < nchq; c += nwib) {
+            const int q = c * 64 + lane;
+            // a record of this chunk that went to the stragglers is handled by its finisher (flag read BEFORE ... see below)
+            const bool valid = q < nq && (tnl[q] & 0x80000000u) == 0u;
+            time_of(q, valid);
+        }
+        } else {
+
         // ---- a2. first evaluation of every record, in sorted order (one layer count per wave) -------
         // GetPTime's branch (:136-153) is taken here, at full lane occupancy.  It also tells which
         // sources are long (bisection first: 2 + up to 20 + up to 16 further evaluations) and which are
@@ -478,7 +731,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             {
                 // every lane of the wave takes part (wave-uniform choice of the divide); dead lanes are restored
                 const Lane<T> keep = s;
-                lane_advance_init(s, f, fp, live);
+                lane_advance_init(t, s, f, fp, live);
                 if (!live)
                     s = keep;
             }
@@ -491,9 +744,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                         k2 |= RTMI_RK_CONV;
                 } else {
                     rp[q] = s.xe;  // BIS0: 1e-10; NEWTON: the first Newton iterate (x == xe)
-                    if (s.st != ST_BIS0)
-                        k2 |= RTMI_RK_SHORT | ((uint32_t)(RTMI_RK_CLASSES - 1) << RTMI_RK_CLASS_SHIFT);
-                    else
+                    if (s.st != ST_BIS0) {
+                        // Newton from p0: two or three more evaluations -- unless the iteration starts where f is steep
+                        // (1 - (p vmax)^2 small at the larger of p0 and the first iterate): those take five on average, up
+                        // to eleven, and go first (a scheduling hint, no result depends on it)
+                        const T yl = (p0 > s.x ? p0 : s.x) * t.VMAX[nl - 1];
+                        const bool lng = T(1.0) - yl * yl < T(0.03);
+                        k2 |= RTMI_RK_SHORT | ((uint32_t)(lng ? 0 : RTMI_RK_CLASSES - 1) << RTMI_RK_CLASS_SHIFT);
+                    } else
                         k2 |= (uint32_t)trip_class(t, nl - 1, s.R, rz[q]) << RTMI_RK_CLASS_SHIFT;
                 }
                 rk[q] = k2;
@@ -851,7 +1109,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
             }
-            lane_advance_solve(s, f, fp);
+            lane_advance_solve(t, s, f, fp);
             ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
@@ -941,6 +1199,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 }
             }
         }
+        }  // RTMI_ENGINE
         __syncthreads();
         if (WANT_SS && !INC) {
             // the squared residuals, added up in SLOT order by all waves: an order that depends on nothing but the
