@@ -103,13 +103,16 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
  * set; nothing of a sweep runs on the host.  A sweep is either ONE persistent cooperative launch in which the workgroups
  * of a chain meet among themselves slot by slot, so chains run ahead of each other (needs the fused kernel path and all
  * workgroups resident), or two launches per slot replayed as a captured hipGraph (RTMI_PT_GRAPH=0: launched one by one).
- * The engines give bit-identical chains; the first rtmi_pt_run of >= 8 sweeps times two sweeps of each (one event
- * synchronisation, once per handle) and keeps the persistent launch unless it is slower -- it is, several times, when
- * other processes share the GPU.  RTMI_PT_PERSISTENT=0 / 1 decides up front instead.
+ * The engines give bit-identical chains; which one a handle uses is measured once: in the first rtmi_pt_run call of
+ * >= 12 sweeps, as soon as the sweeps have their full length (the bound of k that sizes a sweep has reached kmax) and ten
+ * more are to go, five sweeps run persistent and five as per-slot launches -- one warm sweep, then a block of four timed
+ * as a whole, one event synchronisation in all -- and the persistent launch stays unless its block took more than 1.08x
+ * the time per proposal slot (it does, several times over, when other processes share the GPU).  RTMI_PT_PERSISTENT=0 / 1
+ * decides up front instead.
  * The likelihood of a proposal is INCREMENTAL: a birth, death or perturbation changes the model from some depth
  * downwards, and a source above that depth has, bit for bit, the travel time it has under the chain's current model --
  * its squared residual is taken from a per-chain cache in HBM (2 x nchains x ndata doubles) instead of being traced
- * again.  The sampler's sums of squared residuals are EXACT (a 192-bit fixed-point accumulator per lane, wave, workgroup),
+ * again.  The sampler's sums of squared residuals are ORDER-INDEPENDENT (integer sums on a fixed 2^-76 s^2 grid, per lane, wave, workgroup),
  * so their value does not depend on the order of the additions: logL and the chains are those of the full evaluation
  * (RTMI_PT_INCREMENTAL=0 evaluates every proposal over all sources), whatever the launch geometry, knobs or engine.
  *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
@@ -208,13 +211,15 @@ int rtmi_version(void);
  * Sticky fault word of the device code: 0, or a bit mask: bits 1, 2, 4 = a kernel ran out of one of its bounded waits
  * (the hand-over ring of the fused kernel is deadlock-free by construction; the bounds exist so that a fault could never
  * hang the GPU; bit 16: a wait between the workgroups of the persistent sweep kernel -- the sweep was abandoned, the
- * handle's chains are not to be trusted); bit 8 = a row of rtmi_trace_batch_device had d_nlayers outside [1, ld_model - 1].  The host-pointer
+ * handle's chains are not to be trusted and its abort word stays set: DESTROY the handle, rtmi_clear_device_status does not
+ * revive it); bit 8 = a row of rtmi_trace_batch_device had d_nlayers outside [1, ld_model - 1].  The host-pointer
  * entry points check it after their synchronise and fail; callers of the asynchronous device entry points can poll it
  * after their own synchronise.  The word is allocated by rtmi_init or by the first un-captured call of any entry
  * point; a FIRST call made inside a stream capture is refused with RTMI_ERR_BAD_ARG (call rtmi_init before capturing).
  */
 int rtmi_device_status(void);
-/* Resets the fault word (after the caller has dealt with what it reported); returns the value it had. */
+/* Resets the fault word (after the caller has dealt with what it reported -- for bit 16: after the sampler handle that
+ * raised it was destroyed); returns the value it had. */
 int rtmi_clear_device_status(void);
 /* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
 int rtmi_device_cus(void);
@@ -269,6 +274,23 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
 int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayers,
                           const float *d_src_offset, const float *d_src_depth, int64_t nsrc,
                           float *d_timeP, float *d_p_final, void *stream);
+
+/*
+ * Single precision, FAST (opt-in; BASELINE.json configs[4]).  Not the reference's iteration: the same equations
+ * (costFunc subroutineR-quiet.f90:184-202, the travel-time sum :156-166) over the same stack of layers (whichLayer :9-32,
+ * InsertLayer :38-69), solved to single-precision roundoff by a monotone Newton iteration in s = tan(theta) of the stack's
+ * fastest layer, where 1 - p^2 V^2 has no cancellation (csrc/rtmi_f32fast.hip).  Results differ from the reference by what
+ * the reference's own stopping rule leaves (it stops 0.1 m short of the root: median 2e-7 s, 99.9 % below 4e-5 s; where
+ * the reference gives up or accepts a non-converged iterate -- its -999 and its rare gross errors -- this entry point
+ * returns the travel time of the actual ray), and from a converged double-precision solution by < 1e-6 s.  About five
+ * times the throughput of the double-precision path.  Preconditions: at most 63 interfaces, in non-decreasing order from a
+ * depth >= 0, velocities > 0; a model that violates them gets NaN outputs and bit 8 of rtmi_device_status().  -999 is
+ * returned for a source whose ray does not exist (NaN / Inf data; a stack whose fastest layer has no thickness and cannot
+ * reach the offset).  d_p_final (may be NULL) receives the ray parameter (NaN for a source in the top layer).
+ */
+int rtmi_trace_device_f32_fast(const float *d_vels, const float *d_depths, int nlayers,
+                               const float *d_src_offset, const float *d_src_depth, int64_t nsrc,
+                               float *d_timeP, float *d_p_final, void *stream);
 
 /*
  * Many models over one shared source set: what nmodels consecutive calls of

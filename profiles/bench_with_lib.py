@@ -5,5 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracerfortran_amd import raymod
 raymod.LIB_PATH = os.path.abspath(sys.argv[1])
+import ctypes
+_probe = ctypes.CDLL(raymod.LIB_PATH)   # an older build may lack newer entry points: they are not what is being measured
+for _name in [n for n in raymod.SIGNATURES if not hasattr(_probe, n)]:
+    del raymod.SIGNATURES[_name]
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
 runpy.run_path(sys.argv[0], run_name="__main__")

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtmi.so")
 LIB7 = os.path.join(HERE, "librtmi_dff7.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("rtmi_kernels.hip", "rtmi_capi.cpp", "rtmi_pt.hip", "rtmi_comm.cpp")]
+SOURCES = [os.path.join(CSRC, f) for f in ("rtmi_kernels.hip", "rtmi_f32fast.hip", "rtmi_capi.cpp", "rtmi_pt.hip", "rtmi_comm.cpp")]
 SHIM7 = os.path.join(CSRC, "rtmi_dff7_shim.c")
 HEADERS = [os.path.join(CSRC, h) for h in ("rtmi_kernels.h", "rtmi_device.hpp", "rtmi_host.h", "rtmi_pt_rules.h", "rtmi_pt_dev.hpp")] + \
           [os.path.join(os.path.dirname(HERE), "include", "rtmi.h")]

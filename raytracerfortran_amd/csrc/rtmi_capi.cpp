@@ -1018,6 +1018,40 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
     return RTMI_OK;
 }
 
+int rtmi_trace_device_f32_fast(const float *d_vels, const float *d_depths, int nlayers, const float *d_src_offset,
+                               const float *d_src_depth, int64_t nsrc, float *d_timeP, float *d_p_final, void *stream)
+{
+    int rc = check_model(nlayers);
+    if (rc)
+        return rc;
+    if (nlayers > RTMI_F32FAST_MAX_NL)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_trace_device_f32_fast: at most %d interfaces (got %d); use rtmi_trace_device_f32",
+                    RTMI_F32FAST_MAX_NL, nlayers);
+    if (nsrc < 0)
+        return fail(RTMI_ERR_BAD_ARG, "nsrc < 0");
+    if (nsrc == 0)
+        return RTMI_OK;
+    if (!d_vels || !d_depths || !d_src_offset || !d_src_depth || !d_timeP)
+        return fail(RTMI_ERR_BAD_ARG, "NULL device pointer");
+    int *d_status = nullptr;
+    rc = status_word_for((hipStream_t)stream, &d_status);
+    if (rc)
+        return rc;
+    rtmi::F32FastArgs a;
+    memset(&a, 0, sizeof a);
+    a.d_vels = d_vels;
+    a.d_depths = d_depths;
+    a.nlayers = nlayers;
+    a.d_src_offset = d_src_offset;
+    a.d_src_depth = d_src_depth;
+    a.nsrc = nsrc;
+    a.d_timeP = d_timeP;
+    a.d_p_final = d_p_final;
+    a.d_status = d_status;
+    HIP_TRY(rtmi_launch_f32fast(&a, num_cus_for_current_device(), (hipStream_t)stream));
+    return RTMI_OK;
+}
+
 int rtmi_trace_device_f32(const float *d_vels, const float *d_depths, int nlayers, const float *d_src_offset,
                           const float *d_src_depth, int64_t nsrc, float *d_timeP, float *d_p_final, void *stream)
 {

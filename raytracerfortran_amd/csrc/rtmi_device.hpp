@@ -254,7 +254,7 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
         // only orders the work, no result depends on it.
         // The table costs O(nlayers^2) operations per workgroup (approximate single-precision reciprocal and
         // reciprocal square root: a few instructions per pair of layers).
-        const bool hint_unused = false;  // models with the bound of bisection_skip use it for their longest sources only (trip_class)
+        const bool hint_unused = t.SA != nullptr;  // see trip_class
         for (int il = 1 + (int)threadIdx.x; il <= nlayers && !hint_unused; il += blockDim.x) {
             if (nlayers > RTMI_HINT_MAX_NL) {
                 // very deep models: one class for all bisection sources (measured at 1024 interfaces: ordering by
@@ -340,14 +340,12 @@ __device__ __forceinline__ int trip_class(const LayerTable<T> &t, int il, T R, T
     // Models that carry the bound of bisection_skip (<= RTMI_SKIP_MAX_NL interfaces) enter the
     // bisection a trip or two before it ends, whatever the geometry: one class (measured: -9 % on a tempering slot
     // against the three classes below, which sort by the trips that are no longer made).
+    if (t.SA)
+        return RTMI_TRIP_CLASSES - 1;
     const T hl = z - t.D[il - 1];
     const T num = R - (t.PA[il] + hl * t.PC[il]);
     const T hj = t.PH[il];
     const T den = hj > T(0.0) ? hj : hl;
-    // ... except the rays so close to critical that the bisection runs to its last trips and the Newton iteration after it
-    // creeps (8 evaluations on average, up to 17, against 3): those go first, so that they are finished before the queue runs dry
-    if (t.SA)
-        return num > den * T(128.0) ? 0 : RTMI_TRIP_CLASSES - 1;
     int c = RTMI_TRIP_CLASSES - 1;
     c -= (num > den * T(9.51));    // 2^3.25: about 12 evaluations or more
     c -= (num > den * T(64.0));    // 2^6:    about 17.5 or more
@@ -649,81 +647,79 @@ __device__ __forceinline__ bool term_guarded_n(const float (&w)[N], const float 
 __device__ __forceinline__ int hi_word(double v) { return __double2hiint(v); }
 __device__ __forceinline__ int hi_word(float v) { return (int)__float_as_uint(v); }
 
-// ---- exact accumulation of squared residuals (the sampler's likelihood) -----------------------------------------------
-// A 192-bit fixed-point accumulator, least significant bit 2^-128, 64 integer bits: adding non-negative doubles below 2^43
-// to it is EXACT down to 2^-128 (a squared residual of 3e-39 s^2), and integer addition is associative -- the sum of a
-// chain's squared residuals does not depend on the order in which lanes, waves, workgroups or launches of different
-// geometry add them up, nor on whether a residual was computed in this launch or taken from the chain's cache.  flags: 1 a
-// NaN was added (the sum is NaN, as the reference's SUM would be), 2 a term >= 2^43 s^2 (the sum is reported as +Inf).
-struct Acc192 {
-    unsigned long long w0, w1, w2;
-    unsigned int flags;
+// ---- order-independent accumulation of squared residuals (the sampler's likelihood) ---------------------------------------
+// A 124-bit fixed-point accumulator in two words, least significant bit 2^-76 s^2: an addend (>= 0, below 2^20 s^2) is cut to
+// that grid -- a fixed function of the addend alone, |error| < 1.4e-23 s^2, twenty orders below a double's resolution of a
+// chain's sum -- and added as an integer, and integer addition is associative: the sum of a chain's squared residuals does
+// not depend on the order in which lanes, waves, workgroups or launches of different geometry add them up, nor on whether a
+// residual was computed in this launch or taken from the chain's cache.  The two top bits of the high word are flags (the
+// sum itself stays below 2^50 s^2: fewer than 2^30 addends): bit 63 = a NaN was added (the sum is NaN, as the reference's
+// SUM would be), bit 62 = an addend >= 2^20 s^2 (the sum is reported as +Inf).  [Four registers per lane; the 192-bit form
+// of round 2, exact down to 2^-128, took seven and pushed the sampler's kernel into scratch.]
+struct Acc192 {  // (the name of the round-2 form is kept)
+    unsigned long long w0, w1;
 };
+#define RTMI_ACC_NAN (1ull << 63)
+#define RTMI_ACC_INF (1ull << 62)
+#define RTMI_ACC_FLAGS (RTMI_ACC_NAN | RTMI_ACC_INF)
 
 __device__ __forceinline__ Acc192 acc_zero()
 {
     Acc192 a;
-    a.w0 = a.w1 = a.w2 = 0ull;
-    a.flags = 0u;
+    a.w0 = a.w1 = 0ull;
     return a;
 }
 
-__device__ __forceinline__ void acc_add_words(Acc192 &a, unsigned long long b0, unsigned long long b1, unsigned long long b2)
-{
-    unsigned long long t = a.w0 + b0;
-    const unsigned long long c0 = t < b0 ? 1ull : 0ull;
-    a.w0 = t;
-    t = a.w1 + b1;
-    unsigned long long c1 = t < b1 ? 1ull : 0ull;
-    const unsigned long long t2 = t + c0;
-    c1 |= t2 < c0 ? 1ull : 0ull;
-    a.w1 = t2;
-    a.w2 = a.w2 + b2 + c1;
-}
-
+// a += b (flags are OR-ed: the value bits of w1 never carry into them)
 __device__ __forceinline__ void acc_add(Acc192 &a, const Acc192 &b)
 {
-    acc_add_words(a, b.w0, b.w1, b.w2);
-    a.flags |= b.flags;
+    const unsigned long long fl = (a.w1 | b.w1) & RTMI_ACC_FLAGS;
+    const unsigned long long t = a.w0 + b.w0;
+    const unsigned long long c = t < b.w0 ? 1ull : 0ull;
+    a.w0 = t;
+    a.w1 = (((a.w1 & ~RTMI_ACC_FLAGS) + (b.w1 & ~RTMI_ACC_FLAGS) + c) & ~RTMI_ACC_FLAGS) | fl;
 }
 
 // a += x for a squared residual x (>= 0, or NaN)
 __device__ __forceinline__ void acc_add_double(Acc192 &a, double x)
 {
     if (!(x >= 0.0)) {
-        a.flags |= 1u;
+        a.w1 |= RTMI_ACC_NAN;
         return;
     }
-    if (x >= 8796093022208.0) {  // 2^43
-        a.flags |= 2u;
+    if (x >= 1048576.0) {  // 2^20
+        a.w1 |= RTMI_ACC_INF;
         return;
     }
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     const int e = (int)((bits >> 52) & 0x7FFull);
     if (e == 0)
-        return;  // zero or subnormal: below 2^-128
+        return;  // zero or subnormal: below the grid
     unsigned long long m = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;  // x = m 2^(e - 1075)
-    int shift = e - 947;                                                      // position of m's lowest bit above 2^-128
+    int shift = e - 999;                                                      // position of m's lowest bit above 2^-76
     if (shift < 0) {
         if (shift <= -53)
             return;
-        m >>= -shift;
+        m >>= -shift;  // cut to the grid
         shift = 0;
     }
-    const int idx = shift >> 6, s = shift & 63;  // idx 0 or 1 (x < 2^43)
-    const unsigned long long lo = m << s, hi = s ? (m >> (64 - s)) : 0ull;
-    acc_add_words(a, idx == 0 ? lo : 0ull, idx == 0 ? hi : lo, idx == 0 ? 0ull : hi);
+    // x < 2^20: shift <= 43, so m << shift ends below bit 96
+    const unsigned long long lo = m << shift;
+    const unsigned long long hi = shift ? m >> (64 - shift) : 0ull;
+    const unsigned long long t = a.w0 + lo;
+    const unsigned long long c = t < lo ? 1ull : 0ull;
+    a.w0 = t;
+    a.w1 += hi + c;  // no carry reaches the flag bits (see above)
 }
 
-// the accumulated sum as a double: a fixed function of the exact integer
+// the accumulated sum as a double: a fixed function of the integer
 __device__ __forceinline__ double acc_to_double(const Acc192 &a)
 {
-    if (a.flags & 1u)
+    if (a.w1 & RTMI_ACC_NAN)
         return __builtin_nan("");
-    if (a.flags & 2u)
+    if (a.w1 & RTMI_ACC_INF)
         return __builtin_inf();
-    const double lo = __ull2double_rn(a.w1) * 5.421010862427522e-20 + __ull2double_rn(a.w0) * 2.938735877055719e-39;  // 2^-64, 2^-128
-    return __ull2double_rn(a.w2) + lo;
+    return __ull2double_rn(a.w1) * 2.44140625e-4 + __ull2double_rn(a.w0) * 1.3234889800848443e-23;  // 2^-12, 2^-76
 }
 
 // lower end of the guarded range of w = 1 - p^2 v^2
@@ -896,7 +892,6 @@ struct Lane {
     bool conv;
     bool numer_ok;  // hvl and the table products of the stack are inside eval_f_fp's fast-path guard
     bool skip0;     // solvebst's first evaluation, f(x1 = 1d-10) (:354), is provably positive: only its sign is used
-    bool pred_ok;   // the stack and the source are inside the guards of newton_lands_converged
 };
 
 // The source's layer-dependent constants (InsertLayer :38-69 as table lookups).  il = nl - 1 >= 1.
@@ -919,10 +914,6 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
     // (a 1 % margin over all of that) proves f1 > 0 whatever the last bits are, and the evaluation -- one whole trip
     // of the source, for two sources in three -- need not be made.  NaN or Inf anywhere makes the test false.
     s.skip0 = s.R > T(1.01e-10) * (t.PSA[il - 1] + fabs(s.hvl)) && t.VMAX[il] < T(1e7);
-    // guards of newton_lands_converged: f and f' are sums of non-negative terms (sorted interfaces from a non-negative
-    // depth, positive velocities, the source not above its layer's top), everything of moderate magnitude
-    s.pred_ok = std::is_same<T, double>::value && s.numer_ok && t.HVOK[t.nul - 1] == T(2.0) && hl >= T(0.0) &&
-                s.R < T(1e5) && t.VMAX[il] < T(1e7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -947,18 +938,30 @@ __device__ __forceinline__ void lane_setup(Lane<T> &s, const LayerTable<T> &t, i
 // only: in single precision the noise of the sums is of the order of tol.  On the C2 stream this is the last evaluation
 // of 92 % of the sources: 3.85 -> 2.94 evaluations per source in the solve loop (profiles/sim_predict.py).
 // ---------------------------------------------------------------------------------------------
+// the model's part of newton_lands_converged's guards (wave-uniform; the flag stage_model leaves in HVOK[nlayers])
 template <typename T>
-__device__ __forceinline__ bool newton_lands_converged(const LayerTable<T> &t, const Lane<T> &s, T x, T f, T q, T xnew)
+__device__ __forceinline__ bool model_terms_nonneg(const LayerTable<T> &t)
+{
+    return std::is_same<T, double>::value && RTMI_PREDICT && t.HVOK[t.nul - 1] == T(2.0);
+}
+
+template <typename T>
+__device__ __forceinline__ bool newton_lands_converged(const LayerTable<T> &, const Lane<T> &s, T x, T f, T q, T xnew)
 {
     if constexpr (!std::is_same<T, double>::value || !RTMI_PREDICT) {
         return false;
     } else {
-        const T vmax = t.VMAX[s.nfull];
-        const T y = x * vmax;
-        const T w = T(1.0) - y * y;
-        const T b = T(1.5) * (y * vmax) * fabs(f * q);
-        return s.pred_ok && f < T(0.0) && xnew < x && xnew > T(0.0) && w > T(1e-8) && b <= T(0.08) * w && f > T(-1e4) &&
-               fabs(q) > T(1e-9) * x;
+        // in terms of vmi = RN(1/vmax), which the lane holds:  w_min / vmax^2 = (vmi - x)(vmi + x) (1 + O(2.2e-16 / w_min)),
+        // so  B <= 0.08  <=>  x |fx q| <= (0.08 / 1.5) (vmi - x)(vmi + x);  w_min >= (vmi - x) / vmi.  q > 0 (both sums are
+        // negative) makes xnew < x < vmi: no clamp.
+        const T gap = s.vmi - x;
+        const T u = gap * (s.vmi + x);
+        // the lane's part of the guards: no term of f, f' is negative (with the model's part, model_terms_nonneg: sorted
+        // interfaces from a non-negative depth, positive velocities -- the caller's `use_pred` -- the source not above its
+        // layer's top), everything of moderate magnitude (R < 1e5, vmax < 1e7)
+        const bool lane_ok = s.numer_ok && s.hvl >= T(0.0) && s.R < T(1e5) && s.vmi > T(1e-7);
+        return lane_ok && f < T(0.0) && f > T(-1e4) && q > T(1e-9) * x && xnew > T(0.0) && gap > T(1e-8) * s.vmi &&
+               x * fabs(f * q) <= T(0.0533) * u;
     }
 }
 
@@ -1071,7 +1074,7 @@ __device__ __forceinline__ void lane_start(Lane<T> &s, T p0)
 // the fused kernel evaluates ST_INIT in a pass of its own and never meets it in the solve loop.
 enum : int { ADV_ANY = 0, ADV_INIT_ONLY = 1, ADV_NO_INIT = 2 };
 template <int MODE = ADV_ANY, typename T>
-__device__ __forceinline__ void lane_advance(const LayerTable<T> &t, Lane<T> &s, T f, T fp)
+__device__ __forceinline__ void lane_advance(const LayerTable<T> &t, Lane<T> &s, T f, T fp, bool use_pred)
 {
     const int st = s.st;
     const bool isI = MODE == ADV_INIT_ONLY ? true : (MODE == ADV_NO_INIT ? false : st == ST_INIT);
@@ -1107,7 +1110,7 @@ __device__ __forceinline__ void lane_advance(const LayerTable<T> &t, Lane<T> &s,
     const bool n_go = newt && !small;
     T xnew = xN - q;                // x = x - deltax (:298)
     // the next trip of solve's loop would only confirm convergence at xnew (newton_lands_converged): it is not made
-    const bool n_pred = n_go && kN != 15 && newton_lands_converged(t, s, xN, f, q, xnew);
+    const bool n_pred = use_pred && n_go && kN != 15 && newton_lands_converged(t, s, xN, f, q, xnew);
     if (xnew > s.vmi)
         xnew = s.clampv;                    // (:299-304)
 
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ void lane_advance(const LayerTable<T> &t, Lane<T> &s,
                 s.st = ST_DONE;
             } else {
                 T xn = xb2 - q;
-                const bool pred = newton_lands_converged(t, s, xb2, f, q, xn);
+                const bool pred = use_pred && newton_lands_converged(t, s, xb2, f, q, xn);
                 if (xn > s.vmi)
                     xn = s.clampv;
                 s.x = xn;
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ void lane_skip_idle_trips(const LayerTable<T> &t, Lan
 // lane_advance for a lane in ST_INIT (the fused kernel's first-evaluation pass): GetPTime's branch (:136-153) after
 // cf = f(p0), cfp = f'(p0).  Same operations on the same operands as lane_advance.
 template <typename T>
-__device__ __forceinline__ void lane_advance_init(const LayerTable<T> &t, Lane<T> &s, T f, T fp, bool live)
+__device__ __forceinline__ void lane_advance_init(const LayerTable<T> &, Lane<T> &s, T f, T fp, bool live)
 {
     const T q = solver_quotient(f, fp, live);  // cf/cfp (:138)
     const bool neg = f < T(0.0);
@@ -1272,10 +1275,11 @@ __device__ __forceinline__ void lane_advance_init(const LayerTable<T> &t, Lane<T
     const bool newton = neg || check_x < s.safe;  // (:139-144) Newton straight from p0, else bisection first (:145-148)
     T xnew = s.xe - q;                         // solve's first trip: x = p0 - deltax (:298)
     const bool go = newton && !small;
-    const bool pred = go && newton_lands_converged(t, s, s.xe, f, q, xnew);  // the second trip would only confirm convergence
+    // (newton_lands_converged is not consulted here: one source in 700 is that close at p0, and the first-evaluation pass
+    // of a small launch is on its critical path)
     if (xnew > s.vmi)
         xnew = s.clampv;                       // (:299-304)
-    const bool conv = (newton && small) || pred;
+    const bool conv = newton && small;
     s.x = go ? xnew : s.x;                     // converged at p0: x stays p0
     s.xe = go ? xnew : (newton ? s.xe : T(1e-10));
     s.k = go ? 2 : (newton ? 1 : s.k);
@@ -1287,8 +1291,11 @@ __device__ __forceinline__ void lane_advance_init(const LayerTable<T> &t, Lane<T
 // each skipped when no lane of the wave is in that state.  With the longest-first solve order the lanes of a wave
 // are mostly in the same phase of their solves, so most trips execute one block; inside a block the updates are
 // plain masked writes instead of chains of selects.  Same operations on the same operands as lane_advance.
+// `use_pred` (wave-uniform): consult newton_lands_converged.  It pays where a round holds several records per lane (the
+// evaluations it saves are throughput: config 4's share -2 %); a round of about one record per lane lasts as long as
+// its longest source, and there the test only lengthens every trip (tempering slot +4 %), so the launcher leaves it out.
 template <typename T>
-__device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<T> &s, T f, T fp)
+__device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<T> &s, T f, T fp, bool use_pred)
 {
     const int st = s.st;
     const T q = solver_quotient(f, fp, st != ST_DONE);  // deltax of solvebst (:384) and of solve (:294)
@@ -1309,7 +1316,9 @@ __device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<
         const bool fuse = done && (neg || (!zero && jump));
         T xnew = s.xe - q;                   // x = x - deltax (:298)
         // ... and solve's SECOND trip is not made when it would only confirm convergence (newton_lands_converged)
-        const bool pred = fuse && !small && newton_lands_converged(t, s, s.xe, f, q, xnew);
+        bool pred = false;
+        if (use_pred)
+            pred = fuse && !small && newton_lands_converged(t, s, s.xe, f, q, xnew);
         if (xnew > s.vmi)
             xnew = s.clampv;                 // (:299-304)
         const bool f_conv = (fuse && small) || pred, f_go = fuse && !small;
@@ -1324,7 +1333,9 @@ __device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<
         T xnew = s.x - q;                    // x = x - deltax (:298)
         const bool last = (s.k == 15);
         // the next trip would only confirm convergence at xnew (newton_lands_converged): the source is finished now
-        const bool pred = !small && !last && newton_lands_converged(t, s, s.x, f, q, xnew);
+        bool pred = false;
+        if (use_pred)
+            pred = !small && !last && newton_lands_converged(t, s, s.x, f, q, xnew);
         if (xnew > s.vmi)
             xnew = s.clampv;                 // (:299-304)
         s.conv = (small || pred) ? true : s.conv;  // (:288)

@@ -82,7 +82,7 @@ struct FusedArgsT {
     int max_nlayers;               // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers]
     int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
     unsigned long long *d_partial_x;  // [nmodels][grid.x][4] or NULL: the SAMPLER's form of the sums -- per workgroup an exact
-                                      // 192-bit fixed-point sum of squared residuals (rtmi_device.hpp::Acc192: words 0..2, flags)
+                                      // order-independent fixed-point sum of squared residuals (rtmi_device.hpp::Acc192: words 0, 1; 2, 3 unused)
                                       // instead of d_partial; needs d_obs, no d_timeP, T = double, the fused kernel
     const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_partial_x
     T *d_r2cur, *d_r2prop;         // [nmodels][nsrc] squared residuals under the current model / of the proposal
@@ -106,9 +106,26 @@ struct PtSweepArgs {
     int lds_ctl;           // set by the launcher: byte offset of the kernel's own control word in dynamic LDS
 };
 
+// Arguments of the single-precision fast forward model (rtmi_f32fast.hip).  Sorted interfaces, positive velocities.
+#define RTMI_F32FAST_MAX_NL 63
+struct F32FastArgs {
+    const float *d_vels;        // [nlayers + 1]
+    const float *d_depths;      // [nlayers]
+    int nlayers;
+    const float *d_src_offset;  // [nsrc]
+    const float *d_src_depth;   // [nsrc]
+    int64_t nsrc;
+    float *d_timeP;             // [nsrc]
+    float *d_p_final;           // [nsrc] or NULL
+    int *d_status;              // sticky fault word or NULL: bit 8 = the model is not usable (unsorted interfaces, a
+                                // velocity <= 0, NaN): every output is NaN
+};
+
 }  // namespace rtmi
 
 extern "C" {
+hipError_t rtmi_launch_f32fast(const rtmi::F32FastArgs *args, int num_cus, hipStream_t stream);
+size_t rtmi_f32fast_lds_bytes(int nlayers);
 hipError_t rtmi_prepare_kernels();
 int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, int num_cus, int waves_per_simd, int elem_bytes,
                         int *threads, int *slots, size_t *lds_bytes);

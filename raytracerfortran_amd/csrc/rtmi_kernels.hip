@@ -79,12 +79,13 @@ __device__ __forceinline__ T trace_one(const LayerTable<T> &t, int nlayers, T R,
     if (!active || p0 != p0)
         s.st = ST_DONE;
     const int nfull_wave = wave_max_i32(active ? s.nfull : 0);
+    const bool use_pred = model_terms_nonneg(t);  // the plain kernel's trips are as long as their slowest lane: every evaluation counts
 
     while (__any(s.st != ST_DONE)) {
         T f, fp;
         eval_f_fp(t, s.xe, s.nfull, nfull_wave, s.hvl, s.vvl, s.R, s.numer_ok, s.st != ST_DONE, f, fp);
         const bool was_init = s.st == ST_INIT;
-        lane_advance(t, s, f, fp);
+        lane_advance(t, s, f, fp, use_pred);
         if (was_init && s.skip0 && s.st == ST_BIS)  // solvebst entered with f(x1) > 0: idle trips need not be made
             lane_skip_idle_trips(t, s, il, z - t.D[il - 1]);
     }
@@ -207,10 +208,9 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
     return nl_max <= 63 ? nl : (int)(((long long)nl * 63) / nl_max);
 }
 
-#ifndef RTMI_ENGINE
-#define RTMI_ENGINE 0        // solve phase of the fused kernel: 1 = per-wave passes over sorted records, 0 = workgroup queue with lane refill
+#ifndef RTMI_PREFETCH
+#define RTMI_PREFETCH 1      // chunks of source data a wave keeps in flight in the load / sort passes
 #endif
-#define RTMI_STRAGGLERS 24   // (passes) a wave with fewer unfinished sources than this after a pass hands them to the finishers
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..23 (nl <= 1025)
 #define RTMI_RK_NL_MASK 0x7FFu
@@ -240,8 +240,8 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                                            (WANT_SS && !INC) ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx)) {
         if (INC && threadIdx.x == 0) {
             unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
-            o[0] = o[1] = o[2] = 0ull;
-            o[3] = (a.allow_skip && a.nlayers == 0) ? 0ull : 1ull;  // an unusable row: NaN, like the plain form
+            o[0] = o[2] = o[3] = 0ull;
+            o[1] = (a.allow_skip && a.nlayers == 0) ? 0ull : RTMI_ACC_NAN;  // an unusable row: NaN, like the plain form
         }
         return;
     }
@@ -253,7 +253,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     const bool inc = INC && a.d_inc != nullptr;
     Acc192 acc = acc_zero();  // (INC) this thread's squared residuals
     PtInc ic = {};
-    unsigned int n_cached = 0, n_traced = 0;  // this thread's sources (statistics of the incremental likelihood)
+    unsigned int n_cached = 0, n_traced = 0;  // this WAVE's sources (statistics of the incremental likelihood; scalar)
     if (inc) {
         ic = a.d_inc[m];
         a.d_r2cur += (int64_t)m * a.nsrc;
@@ -277,7 +277,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         const int64_t k = chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
-    T z_next = depth_of(0, wib);
+    // a window of RTMI_PREFETCH chunks per wave is kept in flight (C2: a wave's four chunks of the round, all at once)
+    T zw[RTMI_PREFETCH], Rw[RTMI_PREFETCH];
+#pragma unroll
+    for (int j = 0; j < RTMI_PREFETCH; ++j)
+        zw[j] = depth_of(0, wib + j * nwib);
     const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS, a.skiptab != 0);
     stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
@@ -328,16 +332,22 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             stamps[0] = clock64();
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t mycnt = 0;
-        if (j0 > 0)
-            z_next = depth_of(j0, wib);
+        if (j0 > 0) {
+#pragma unroll
+            for (int j = 0; j < RTMI_PREFETCH; ++j)
+                zw[j] = depth_of(j0, wib + j * nwib);
+        }
         for (int c = wib; c < CH; c += nwib) {
             const int64_t chunk = b + (j0 + c) * nblocks;
             if (chunk >= nchunks)
                 break;
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const T z = z_next;
-            z_next = depth_of(j0, c + nwib);
+            const T z = zw[0];
+#pragma unroll
+            for (int j = 0; j + 1 < RTMI_PREFETCH; ++j)
+                zw[j] = zw[j + 1];
+            zw[RTMI_PREFETCH - 1] = depth_of(j0, c + RTMI_PREFETCH * nwib);
             // incremental likelihood: a source the proposal does not affect is neither located nor sorted (its squared
             // residual is added from the cache in the second pass)
             const bool unaffected = inc && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
@@ -360,8 +370,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             tnl[c * 64 + lane] = (uint32_t)nl | (rank << 11);  // nl <= 1025, rank < 8192
         }
         hist[wib * 64 + lane] = mycnt;
-        T R_next = offset_of(j0, wib);  // in flight during the scan
-        z_next = depth_of(j0, wib);
+#pragma unroll
+        for (int j = 0; j < RTMI_PREFETCH; ++j) {  // in flight during the scan
+            Rw[j] = offset_of(j0, wib + j * nwib);
+            zw[j] = depth_of(j0, wib + j * nwib);
+        }
         __syncthreads();
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[4] = clock64();  // depths loaded, bins counted
@@ -402,28 +415,36 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 break;
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const T R = R_next, z = z_next;
-            R_next = offset_of(j0, c + nwib);
-            z_next = depth_of(j0, c + nwib);
+            const T R = Rw[0], z = zw[0];
+#pragma unroll
+            for (int j = 0; j + 1 < RTMI_PREFETCH; ++j) {
+                Rw[j] = Rw[j + 1];
+                zw[j] = zw[j + 1];
+            }
+            Rw[RTMI_PREFETCH - 1] = offset_of(j0, c + RTMI_PREFETCH * nwib);
+            zw[RTMI_PREFETCH - 1] = depth_of(j0, c + RTMI_PREFETCH * nwib);
             const uint32_t packed = valid ? tnl[c * 64 + lane] : 1u;
             const int nl = (int)(packed & 0x7FFu);
             // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
             const uint32_t pos = hist[wib * 64 + bin_of(nl, nl_max)] + (packed >> 11);
+            // (incremental likelihood) not affected by the proposal, as in the first pass; counted per wave
+            const bool cached = inc && valid && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+            if (inc) {
+                const unsigned long long cb = __ballot(cached), vb = __ballot(valid);
+                n_cached += (unsigned int)__popcll(cb);
+                n_traced += (unsigned int)__popcll(vb & ~cb);
+            }
             if (valid) {
-                bool cached = false;
                 T r2c = T(0.0);
                 if (inc) {
                     // residuals of the last accepted proposal that are still in r2prop: this source's moves to r2cur now
                     const bool moved = ic.pending && !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
-                    cached = (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;  // as in the first pass
                     if (moved) {
                         r2c = a.d_r2prop[k];
                         a.d_r2cur[k] = r2c;
                     } else if (cached) {
                         r2c = a.d_r2cur[k];
                     }
-                    n_cached += cached ? 1u : 0u;
-                    n_traced += cached ? 0u : 1u;
                 }
                 if (cached) {
                     if constexpr (INC)
@@ -457,255 +478,6 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[5] = clock64();  // records in their slots, p0 computed
         const int nq = __builtin_amdgcn_readfirstlane((int)qctl[1]);  // wave-uniform values are kept in SGPRs
-
-        if constexpr (RTMI_ENGINE == 1) {
-        // ---- P. the solve as per-wave PASSES over sorted records (no queue, no hand-overs, no barriers) ------------
-        // With the evaluations that need not be made gone (bisection_skip, the fused first iterations, the predicted
-        // last one: newton_lands_converged) a source takes 2.9 evaluations after its first, nearly all sources 2 ... 4.
-        // So every wave keeps to ITS OWN chunks of the sorted records (chunk c = slots 64 c ..., one layer count) from
-        // here to the travel times:
-        //   pass 0    evaluate at p0 -- GetPTime's branch (:136-153), solve's first trip or solvebst's entry with the
-        //             idle trips skipped -- park the solver state in the record (rp = x or the bracket end, tnl = state
-        //             word; dx is +-(x2 - x1) 2^-k exactly) and list the unfinished records, in slot order;
-        //   pass n    walk that list 64 records at a time (still sorted by layer count: one trip count per wave and no
-        //             padded terms), evaluate, advance, park, compact the list in place;
-        //   the last few sources of a wave (fewer than RTMI_STRAGGLERS left after a pass) go to a list of the
-        //             workgroup; the last waves to arrive there finish them, lanes keeping their source to the end;
-        //   travel times of the wave's own chunks (the finished records; the stragglers' by whoever finished them).
-        // Waves never wait for each other before the end of the round (the finishers wait for the last arrivals only).
-        typedef __attribute__((address_space(3))) uint32_t lds_u32p;
-        volatile lds_u32p *sctl = (volatile lds_u32p *)(hist + 512);     // [0] stragglers listed, [1] waves arrived
-        uint16_t *slist = reinterpret_cast<uint16_t *>(hist);            // <= 16 x (RTMI_STRAGGLERS - 1) slots
-        const int nchq = (nq + 63) >> 6;
-        if (threadIdx.x == 0) {
-            sctl[0] = 0;
-            sctl[1] = 0;
-        }
-        // hist (the sort's slot table) is free once every wave has placed its records: that was the barrier above; the
-        // two control words are first touched after at least one pass, i.e. after thread 0's stores (same wave: program
-        // order; other waves: they arrive after their passes -- and the finishers re-read under a fence)
-        __syncthreads();
-        const int qd = nchq / nwib, rm = nchq % nwib;
-        uint16_t *mylist = order + 64 * (wib * qd + (wib < rm ? wib : rm));  // this wave's chunks, as many slots
-        int nlist = 0;
-        unsigned long long dg_iters = 0, dg_busy = 0, dg_trips = 0, dg_terms = 0;
-        auto diag_trip = [&](bool busy, int nfw, int nfull) {
-            if (DIAG && fine) {
-                ++dg_iters;
-                dg_busy += (unsigned long long)__popcll(__ballot(busy));
-                dg_trips += (unsigned long long)(nfw + 1);
-                int terms = busy ? nfull + 1 : 0;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
-                    terms += __shfl_xor(terms, off, 64);
-                dg_terms += (unsigned long long)terms;
-            }
-        };
-        // park the state of an unfinished source / publish a finished one
-        auto park = [&](int q, uint32_t key, const Lane<T> &s) {
-            if (s.st == ST_DONE) {
-                rp[q] = s.x;
-                rk[q] = key | (s.conv ? (RTMI_RK_DONE | RTMI_RK_CONV) : RTMI_RK_DONE);
-            } else {
-                rp[q] = (s.st == ST_BIS) ? s.xb : s.x;  // BIS0: unused (xe = 1d-10)
-                tnl[q] = (uint32_t)s.st | ((uint32_t)s.k << 8) | (s.dx > T(0.0) ? 1u << 16 : 0u) | (s.conv ? 1u << 17 : 0u);
-            }
-        };
-        // the solver state of record q back in a lane
-        auto unpark = [&](int q, bool valid, Lane<T> &s) -> uint32_t {
-            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
-            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
-            const uint32_t sw = valid ? tnl[q] : (uint32_t)ST_DONE;
-            const T xv = valid ? rp[q] : T(0.0);
-            s.st = (int)(sw & 0xFFu);
-            s.k = (int)((sw >> 8) & 0xFFu);
-            s.conv = ((sw >> 17) & 1u) != 0u;
-            const T e2 = s.vmi - T(1e-12), e21 = e2 - T(1e-10);   // as lane_enter_bisection
-            const T dxb = ldexp((sw >> 16) & 1u ? e21 : -e21, -s.k);  // halvings are exact
-            const bool bis = s.st == ST_BIS;
-            s.xb = bis ? xv : T(0.0);
-            s.dx = bis ? dxb : T(0.0);
-            s.x = xv;
-            s.xe = bis ? xv + dxb : (s.st == ST_BIS0 ? T(1e-10) : xv);
-            return key;
-        };
-        // ---- pass 0: first evaluation of the wave's chunks
-        for (int c = wib; c < nchq; c += nwib) {
-            const int q = c * 64 + lane;
-            const bool valid = q < nq;
-            Lane<T> s;
-            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
-            const T p0 = valid ? rp[q] : T(0.0);
-            const T zq = valid ? rz[q] : T(1.0);
-            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), zq);
-            lane_start(s, p0);
-            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
-            if (!live)
-                s.st = ST_DONE;
-            const int nfw = wave_max_i32(live ? s.nfull : 0);
-            diag_trip(live, nfw, s.nfull);
-            T f, fp;
-            eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, live, f, fp);
-            {
-                const Lane<T> keep = s;  // every lane takes part (wave-uniform choice of the divide); dead lanes are restored
-                lane_advance_init(t, s, f, fp, live);
-                if (!live)
-                    s = keep;
-            }
-            if (live && s.st == ST_BIS0 && s.skip0) {
-                lane_enter_bisection(s, false);  // f(1e-10) > 0 without evaluating it (lane_setup)
-                lane_skip_idle_trips(t, s, nl - 1, zq - t.D[nl - 2]);
-            }
-            const bool todo = valid && s.st != ST_DONE;
-            if (valid)
-                park(q, key, s);
-            const unsigned long long tb = __ballot(todo);
-            if (todo)
-                mylist[nlist + __popcll(tb & lt_mask)] = (uint16_t)q;
-            nlist += __popcll(tb);
-        }
-        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
-            stamps[6] = stamps[1] = clock64();  // first evaluation done (wave 0)
-        // ---- passes 1, 2, ...
-        int pass = 0;
-#pragma unroll 1
-        while (nlist > 0) {
-            if (nlist < RTMI_STRAGGLERS && pass >= 1)
-                break;
-            ++pass;
-            int wr = 0;
-#pragma unroll 1
-            for (int r = 0; r < nlist; r += 64) {
-                const bool valid = r + lane < nlist;
-                const int q = valid ? (int)mylist[r + lane] : 0;
-                Lane<T> s;
-                const uint32_t key = unpark(q, valid, s);
-                const int nfw = wave_max_i32(valid ? s.nfull : 0);
-                diag_trip(valid, nfw, s.nfull);
-                T f, fp;
-                eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, valid, f, fp);
-                lane_advance_solve(t, s, f, fp);
-                const bool todo = valid && s.st != ST_DONE;
-                if (valid)
-                    park(q, key, s);
-                const unsigned long long tb = __ballot(todo);
-                if (todo)
-                    mylist[wr + __popcll(tb & lt_mask)] = (uint16_t)q;  // wr <= r: the list is compacted in place
-                wr += __popcll(tb);
-            }
-            nlist = wr;
-        }
-        if (DIAG && stamps && j0 == 0 && lane == 0)
-            stamps[8 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave's passes are over
-        // ---- the wave's last sources go to the workgroup's list; the last NF waves to arrive finish them
-        int arrival = 0, sbase = 0;
-        if (lane == 0) {
-            if (nlist > 0)
-                sbase = (int)atomicAdd(hist + 512, (uint32_t)nlist);
-        }
-        sbase = __builtin_amdgcn_readfirstlane(sbase);
-        if (lane < nlist) {  // nlist < RTMI_STRAGGLERS <= 64
-            const uint16_t q = mylist[lane];
-            slist[sbase + lane] = q;
-            tnl[q] |= 0x80000000u;  // handed over: its travel time is the finisher's business
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0)
-            arrival = (int)atomicAdd(hist + 513, 1u);
-        arrival = __builtin_amdgcn_readfirstlane(arrival);
-        const int NF = nwib < 4 ? nwib : 4;
-        const int fin = arrival - (nwib - NF);  // >= 0: this wave is finisher number `fin`
-        if (fin >= 0) {
-            int polls = 0;
-#pragma unroll 1
-            while ((int)sctl[1] < nwib) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++polls > (1 << 24)) {  // never expected: every wave arrives
-                    if (a.d_status && lane == 0)
-                        atomicOr(a.d_status, 4);
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int total = (int)sctl[0];
-#pragma unroll 1
-            for (int g = fin * 64; g < total; g += NF * 64) {
-                const bool valid = g + lane < total;
-                const int q = valid ? (int)slist[g + lane] : 0;
-                Lane<T> s;
-                const uint32_t key = unpark(q, valid, s);
-#pragma unroll 1
-                while (__any(s.st != ST_DONE)) {
-                    const bool busy = s.st != ST_DONE;
-                    const int nfw = wave_max_i32(busy ? s.nfull : 0);
-                    diag_trip(busy, nfw, s.nfull);
-                    T f, fp;
-                    eval_f_fp<ROWS>(t, s.xe, s.nfull, nfw, s.hvl, s.vvl, s.R, s.numer_ok, busy, f, fp);
-                    lane_advance_solve(t, s, f, fp);
-                }
-                if (valid)
-                    park(q, key, s);
-            }
-        }
-        if (DIAG && stamps && j0 == 0 && lane == 0) {
-            stamps[9 + RTMI_STAMPS_PER_WAVE * wib] = clock64();  // this wave's last source finished
-            stamps[10 + RTMI_STAMPS_PER_WAVE * wib] = dg_iters;
-            stamps[11 + RTMI_STAMPS_PER_WAVE * wib] = dg_busy;
-            stamps[12 + RTMI_STAMPS_PER_WAVE * wib] = dg_trips;
-            stamps[13 + RTMI_STAMPS_PER_WAVE * wib] = dg_terms;
-        }
-        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
-            stamps[2] = clock64();
-        // ---- c. travel times of the wave's own chunks (the finished records), then of the stragglers it finished
-        auto time_of = [&](int q, bool valid) {
-            const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
-            const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
-            const T p = valid ? rp[q] : T(0.0);
-            const T z = valid ? rz[q] : T(1.0);
-            const int nfw = wave_max_i32(valid ? il : 0);
-            T tt = travel_time(t, p, il, nfw, il, z, valid);
-            if (!(key & RTMI_RK_CONV))
-                tt = -T(999.0);
-            if (valid) {
-                const int loc = (int)(key & RTMI_RK_LOC_MASK);
-                const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
-                if (WANT_T)
-                    a.d_timeP[k] = tt;
-                if (WANT_P)
-                    a.d_p_final[k] = p;
-                if (WANT_SS) {
-                    const T r = a.d_obs[k] - tt;
-                    if constexpr (INC) {
-                        acc_add_double(acc, (double)(r * r));
-                        if (inc)
-                            a.d_r2prop[k] = r * r;
-                    } else {
-                        rR[q] = r * r;  // the record's R is not needed any more
-                    }
-                }
-            }
-        };
-        // the stragglers of this wave's chunks are not DONE yet (or were finished by this very wave: they are in its
-        // groups below): the flag is read once, before the finisher part publishes anything for them
-        if (fin >= 0) {
-            // a finisher first deals with what only it can do ...
-            const int total = (int)sctl[0];
-#pragma unroll 1
-            for (int g = fin * 64; g < total; g += NF * 64) {
-                const bool valid = g + lane < total;
-                time_of(valid ? (int)slist[g + lane] : 0, valid);
-            }
-        }
-#pragma unroll 1
-        for (int c = wib; c < nchq; c += nwib) {
-            const int q = c * 64 + lane;
-            // a record of this chunk that went to the stragglers is handled by its finisher (flag read BEFORE ... see below)
-            const bool valid = q < nq && (tnl[q] & 0x80000000u) == 0u;
-            time_of(q, valid);
-        }
-        } else {
 
         // ---- a2. first evaluation of every record, in sorted order (one layer count per wave) -------
         // GetPTime's branch (:136-153) is taken here, at full lane occupancy.  It also tells which
@@ -744,14 +516,9 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                         k2 |= RTMI_RK_CONV;
                 } else {
                     rp[q] = s.xe;  // BIS0: 1e-10; NEWTON: the first Newton iterate (x == xe)
-                    if (s.st != ST_BIS0) {
-                        // Newton from p0: two or three more evaluations -- unless the iteration starts where f is steep
-                        // (1 - (p vmax)^2 small at the larger of p0 and the first iterate): those take five on average, up
-                        // to eleven, and go first (a scheduling hint, no result depends on it)
-                        const T yl = (p0 > s.x ? p0 : s.x) * t.VMAX[nl - 1];
-                        const bool lng = T(1.0) - yl * yl < T(0.03);
-                        k2 |= RTMI_RK_SHORT | ((uint32_t)(lng ? 0 : RTMI_RK_CLASSES - 1) << RTMI_RK_CLASS_SHIFT);
-                    } else
+                    if (s.st != ST_BIS0)
+                        k2 |= RTMI_RK_SHORT | ((uint32_t)(RTMI_RK_CLASSES - 1) << RTMI_RK_CLASS_SHIFT);
+                    else
                         k2 |= (uint32_t)trip_class(t, nl - 1, s.R, rz[q]) << RTMI_RK_CLASS_SHIFT;
                 }
                 rk[q] = k2;
@@ -864,6 +631,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         // hand-overs pay once a round holds at least a record per lane (drain) or two (promotion); below that
         // every wave is in its end-game from the start
         const int promote_age = n_todo >= 2 * (int)blockDim.x ? a.promote_age : 0;
+        const bool use_pred = n_todo >= 2 * (int)blockDim.x && model_terms_nonneg(t);  // see lane_advance_solve
         const bool split = nwib > 4 && n_todo >= (int)blockDim.x && (a.retire_max > 0 || promote_age > 0);
         const bool local = split && wib >= 4;
         const bool express = split && wib < 4;
@@ -1109,7 +877,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 dg_t1 = clock64();
                 dg_sec[5] += dg_t1 - dg_t0;
             }
-            lane_advance_solve(t, s, f, fp);
+            lane_advance_solve(t, s, f, fp, use_pred);
             ++age;
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
@@ -1199,7 +967,6 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 }
             }
         }
-        }  // RTMI_ENGINE
         __syncthreads();
         if (WANT_SS && !INC) {
             // the squared residuals, added up in SLOT order by all waves: an order that depends on nothing but the
@@ -1213,29 +980,23 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     }
 
     if constexpr (INC) {
-        // The sampler's form: exact sums (Acc192) -- butterfly over the lanes, the waves through LDS, one record of four
-        // words per workgroup; any order would give the same words.  Statistics ride along (no atomics: the launches of a
-        // handle are stream-ordered and every workgroup owns its words).
+        // The sampler's form: order-independent sums (Acc192) -- butterfly over the lanes, the waves through LDS, one record
+        // of four words per workgroup (two used); any order would give the same words.  Statistics ride along (no atomics:
+        // the launches of a handle are stream-ordered and every workgroup owns its words).
         const bool counting = inc && a.d_inc_counts != nullptr;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             Acc192 o;
             o.w0 = __shfl_xor(acc.w0, off, 64);
             o.w1 = __shfl_xor(acc.w1, off, 64);
-            o.w2 = __shfl_xor(acc.w2, off, 64);
-            o.flags = __shfl_xor(acc.flags, off, 64);
             acc_add(acc, o);
-            n_cached += __shfl_xor(n_cached, off, 64);
-            n_traced += __shfl_xor(n_traced, off, 64);
         }
         unsigned long long *wx = reinterpret_cast<unsigned long long *>(rR);  // the record area is free now
         if (lane == 0) {
-            wx[6 * wib + 0] = acc.w0;
-            wx[6 * wib + 1] = acc.w1;
-            wx[6 * wib + 2] = acc.w2;
-            wx[6 * wib + 3] = acc.flags;
-            wx[6 * wib + 4] = n_traced;
-            wx[6 * wib + 5] = n_cached;
+            wx[4 * wib + 0] = acc.w0;
+            wx[4 * wib + 1] = acc.w1;
+            wx[4 * wib + 2] = n_traced;
+            wx[4 * wib + 3] = n_cached;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1243,19 +1004,17 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             unsigned long long tr = 0, ca = 0;
             for (int w = 0; w < nwib; ++w) {
                 Acc192 o;
-                o.w0 = wx[6 * w + 0];
-                o.w1 = wx[6 * w + 1];
-                o.w2 = wx[6 * w + 2];
-                o.flags = (unsigned int)wx[6 * w + 3];
+                o.w0 = wx[4 * w + 0];
+                o.w1 = wx[4 * w + 1];
                 acc_add(tot, o);
-                tr += wx[6 * w + 4];
-                ca += wx[6 * w + 5];
+                tr += wx[4 * w + 2];
+                ca += wx[4 * w + 3];
             }
             unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
             o[0] = tot.w0;
             o[1] = tot.w1;
-            o[2] = tot.w2;
-            o[3] = tot.flags;
+            o[2] = 0ull;
+            o[3] = 0ull;
             if (counting) {
                 unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * gx + bx);
                 oc[0] += tr;
@@ -1796,8 +1555,7 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
             fprintf(stderr, "rtmi_launch_pt_sweep: geometry gx %d (sweep %d), lds %zu, threads %d\n", gx, ws.gx, lds_bytes, threads);
         return hipErrorInvalidValue;
     }
-    // one round per evaluation only: a chain's share of the sources must fit the workgroup's LDS (it does for every
-    // shape the per-slot launches run in one round; otherwise leave it to them)
+    // (a chain's share of the sources may take several rounds of its workgroups' LDS: fused_body loops over them)
     ws.xcd_map = (nchains % 8 == 0) ? 1 : 0;  // measured: 1.18 ms per sweep against 1.21 with a chain spread over the XCDs
     const void *fn = a.d_partial_x ? (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, true>)
                                        : reinterpret_cast<const void *>(&pt_sweep_kernel<false, true>))

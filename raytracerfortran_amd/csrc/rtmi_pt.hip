@@ -451,16 +451,32 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess &&
               hipMalloc((void **)&h->d_inc, nc * sizeof(rtmi::PtInc)) == hipSuccess &&
               hipMalloc((void **)&h->d_cache_valid, nc * sizeof(int)) == hipSuccess &&
-              hipMalloc((void **)&h->d_inc_counts, 2 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess &&
-              (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess) &&
-              hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) == hipSuccess;
+              (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess);
+    // The residual cache of the incremental likelihood (2 x nchains x nsrc doubles) and its counters exist only where they
+    // are read: the incremental likelihood switched on AND the fused kernel's sampler form (exact sums).  A cache that does
+    // not fit (many chains over 1e6+ sources) is not an error: the handle evaluates every proposal in full instead.
+    if (ok && h->incremental && fused_path) {
+        if (hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&h->d_inc_counts, 2 * nc * (size_t)gx * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->d_r2)
+                (void)hipFree(h->d_r2);
+            h->d_r2 = nullptr;
+            h->d_inc_counts = nullptr;
+            h->incremental = false;
+            fprintf(stderr, "rtmi_pt_create: no room for the residual cache (%.1f GiB): every proposal is evaluated over all sources\n",
+                    (double)(2 * nc * n * sizeof(double)) / (1024.0 * 1024.0 * 1024.0));
+        }
+    } else {
+        h->incremental = false;
+    }
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_inc, 0, nc * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_cache_valid, 0, nc * sizeof(int), h->stream) == hipSuccess &&
-             hipMemsetAsync(h->d_inc_counts, 0, 2 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             (!h->d_inc_counts || hipMemsetAsync(h->d_inc_counts, 0, 2 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess) &&
              (!h->d_partial_x || hipMemsetAsync(h->d_partial_x, 0, 4 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess) &&
-             hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess;
+             (!h->d_r2 || hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess);
     if (ok) {
         // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
         ok = hipMemcpyAsync(h->d_set, c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) == hipSuccess &&
@@ -959,6 +975,9 @@ int rtmi_pt_likelihood_counts(const rtmi_pt *hc, int64_t *traced, int64_t *cache
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    *traced = *cached = 0;
+    if (!h->d_inc_counts)  // the incremental likelihood is off for this handle
+        return RTMI_OK;
     std::vector<unsigned long long> c((size_t)2 * h->nchains * h->d.gx);  // one pair per workgroup
     HIP_TRY(hipMemcpy(c.data(), h->d_inc_counts, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long tr = 0, ca = 0;

@@ -94,8 +94,6 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 rtmi::Acc192 o;
                 o.w0 = w[0];
                 o.w1 = w[1];
-                o.w2 = w[2];
-                o.flags = (unsigned int)w[3];
                 rtmi::acc_add(tot, o);
             }
             part = rtmi::acc_to_double(tot);
@@ -109,7 +107,10 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 
     // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
     if (decide != PT_NONE && act != 0) {
-        const double logl_new = R::gaussian_loglike(part, d.ndata, sd);
+        // a NaN likelihood (NaN data, an unusable model row) is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
+        double logl_new = R::gaussian_loglike(part, d.ndata, sd);
+        if (logl_new != logl_new)
+            logl_new = -1.7976931348623157e308;
         bool took = act == 2;  // the evaluated model is (now) the chain's current model
         if (act == 2) {
             ss = part;
@@ -120,7 +121,9 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 lr = 50.0;
             if (lead)
                 st[2 * decide + 1] += 1;
-            if (!(R::philox_uniform(rng) >= exp(lr))) {  // accept unless u >= exp(logPr + beta (logL' - logL))
+            const double u_acc = R::philox_uniform(rng);
+            // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects
+            if (lr == lr && !(u_acc >= exp(lr))) {
                 k = pk;
                 ss = part;
                 logL = logl_new;
@@ -165,11 +168,14 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
             if (lead)
                 st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
-                const double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
+                double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
+                if (logl_new != logl_new)
+                    logl_new = -1.7976931348623157e308;  // as above
                 double lr = (logl_new - logL) * beta;
                 if (lr > 50.0)
                     lr = 50.0;
-                if (!(R::philox_uniform(rng) >= exp(lr))) {
+                const double u_acc = R::philox_uniform(rng);
+                if (lr == lr && !(u_acc >= exp(lr))) {
                     sd = sd_new;
                     logL = logl_new;
                     if (lead)
@@ -210,7 +216,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     };
     const double zi0 = zi;  // this lane's node depth before the move
     const double dl_cur = k == 1 ? 9999.9 : group_max((i >= 1 && i < k) ? zi : -INFINITY);
-    int moved_node = 0;     // death: the removed node; perturbation: the node
+    const double zmin_cur = -group_max(i < k ? -zi : -INFINITY);  // the shallowest node: its velocity is the TOP layer's
+    int moved_node = 0;     // death: the removed node; perturbation: the node; birth: the new node
     double zthr = -INFINITY;
     int qk = k;
     double lp = 0.0;
@@ -236,6 +243,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 qk = k + 1;
                 lp = lpk_kp - lpk_k;
                 have = true;
+                moved_node = k;
                 zthr = zn;
             } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
                 int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
@@ -266,11 +274,11 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
         moved_node = ivo;
         zthr = INFINITY;      // = min(old, new depth) of the node (a velocity leaves the depth as it is): from its lane below
     }
+    const double z_old_moved = __shfl(zi0, gbase + (moved_node & (G - 1)), 64);
     {
-        const double z_old = __shfl(zi0, gbase + (moved_node & (G - 1)), 64);
         const double z_new = __shfl(zi, gbase + (moved_node & (G - 1)), 64);
         if (zthr == INFINITY)
-            zthr = (propose == PT_BD) ? z_old : fmin(z_old, z_new);
+            zthr = (propose == PT_BD) ? z_old_moved : fmin(z_old_moved, z_new);
         if (!cache_ok || !(zthr == zthr))
             zthr = -INFINITY;  // no valid cache yet (or a NaN depth): evaluate in full
     }
@@ -291,6 +299,18 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
             prev = zj;
     }
     bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
+    // The node of rank 0 gives the top layer its velocity and its depth is not an interface (pack_model): a move that
+    // involves the shallowest node of the current model (its removal, its velocity, its depth) or makes a node the
+    // shallowest of the proposed one changes the model from the surface downwards, whatever that node's depth is --
+    // with the usual node 0 at depth 0 this is zthr = 0 anyway; a chain set up with its first node deeper, or with a node
+    // above it, gets a full evaluation instead of a cache that is silently wrong.
+    {
+        const int r_moved = __shfl(r, gbase + (moved_node & (G - 1)), 64);  // (birth, perturbation: rank in the proposed model)
+        const bool removed = propose == PT_BD && qk < k;
+        const bool touches_top = have && ((moved_node < k && z_old_moved <= zmin_cur) || (!removed && r_moved == 0));
+        if (touches_top)
+            zthr = -INFINITY;
+    }
     const double dl_all = group_max((in && i >= 1) ? zi : -INFINITY);
     const double dl_new = qk == 1 ? 9999.9 : dl_all;
     const bool ok = have && (__ballot(bad) & gmask) == 0ull;

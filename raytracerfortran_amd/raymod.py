@@ -78,6 +78,7 @@ SIGNATURES = {
     "rtmi_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "rtmi_trace_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_device_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    "rtmi_trace_device_f32_fast": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "rtmi_trace_batch_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64,
                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtmi_trace_batch_work_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
@@ -437,9 +438,11 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(s.cuda_stream)
 
 
-def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, stream=None):
+def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, stream=None, fast=False):
     """One forward evaluation on resident data (rtmi_trace_device).  Asynchronous on `stream`
-    (default: torch's current stream).  Returns timeP."""
+    (default: torch's current stream).  Returns timeP.  float32 tensors take rtmi_trace_device_f32 (the reference's
+    iteration in single precision) or, with fast=True, rtmi_trace_device_f32_fast (the same equations solved to
+    single-precision roundoff; not the reference's iterates -- see include/rtmi.h)."""
     import torch
     lib = load_library()
     nlayers = int(depths.numel())
@@ -455,7 +458,9 @@ def trace_device(vels, depths, src_offset, src_depth, timeP=None, p_final=None, 
         timeP = torch.empty(n, dtype=f64, device=src_offset.device)
     if timeP.numel() < n or (p_final is not None and p_final.numel() < n):
         raise ValueError("output too small")
-    fn = lib.rtmi_trace_device if f64 == torch.float64 else lib.rtmi_trace_device_f32
+    if fast and f64 != torch.float32:
+        raise ValueError("fast=True is the single-precision fast path: pass float32 tensors")
+    fn = lib.rtmi_trace_device if f64 == torch.float64 else (lib.rtmi_trace_device_f32_fast if fast else lib.rtmi_trace_device_f32)
     _check(fn(_ptr(vels, f64, "vels"), _ptr(depths, f64, "depths"), nlayers, _ptr(src_offset, f64, "src_offset"),
               _ptr(src_depth, f64, "src_depth"), n, _ptr(timeP, f64, "timeP"), _ptr(p_final, f64, "p_final"),
               _stream_ptr(stream)))

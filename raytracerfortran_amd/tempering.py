@@ -32,6 +32,7 @@ reference is therefore statistical, not bitwise (its RANDOM_NUMBER streams are c
 from __future__ import annotations
 
 import math
+import sys
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -97,8 +98,15 @@ def inside_bounds(nodes: np.ndarray, pr: Prior) -> bool:
 
 
 def gaussian_loglike(ss: float, n: int, sd: float) -> float:
-    """loglhood.f90:194-196 with the overflow-free normalisation."""
-    return -0.5 * n * LOG_2PI - (ss / (2.0 * sd * sd) + n * math.log(sd))
+    """loglhood.f90:194-196 with the overflow-free normalisation; a NaN likelihood is the
+    reference's -HUGE(1._RP) (loglhood.f90:197-200): such a model is never accepted."""
+    ll = -0.5 * n * LOG_2PI - (ss / (2.0 * sd * sd) + n * math.log(sd))
+    return -sys.float_info.max if ll != ll else ll
+
+
+def mh_accept(u: float, log_ratio: float) -> bool:
+    """accept unless u >= exp(log ratio) (prjmh_temper_rf.f90:697-706); a NaN ratio (-HUGE against -HUGE) rejects."""
+    return log_ratio == log_ratio and not (u >= math.exp(min(log_ratio, 50.0)))
 
 
 class GpuEvaluator:
@@ -208,7 +216,7 @@ class Sampler:
             logl_new = gaussian_loglike(float(s), self.ndata, c.sd)
             log_ratio = lp + (logl_new - c.logL) * self.beta(i)
             self.stats["prop_" + kind] += 1
-            if not (self.rng.random() >= math.exp(min(log_ratio, 50.0))):
+            if mh_accept(self.rng.random(), log_ratio):
                 c.nodes, c.ss, c.logL = nodes, float(s), logl_new
                 self.stats["acc_" + kind] += 1
 
@@ -269,7 +277,7 @@ class Sampler:
                 self.stats["prop_sd"] += 1
                 if pr.sdmin <= sd_new <= pr.sdmax:
                     logl_new = gaussian_loglike(c.ss, self.ndata, sd_new)
-                    if not (rng.random() >= math.exp(min((logl_new - c.logL) * self.beta(i), 50.0))):
+                    if mh_accept(rng.random(), (logl_new - c.logL) * self.beta(i)):
                         c.sd, c.logL = sd_new, logl_new
                         self.stats["acc_sd"] += 1
 
@@ -310,7 +318,7 @@ class Sampler:
             self.sweep()
             if (it + 1) % swap_every == 0 and self.nchains_total > 1:
                 self.swap_round()
-            if it >= burnin and (it - burnin) % thin == 0:
+            if it >= burnin and (it - burnin + 1) % thin == 0:  # after every thin-th sweep (prjmh_temper_rf.f90:329-389)
                 for i, c in enumerate(self.chains):
                     if self.level[self.first + i] == 0:
                         s = c.nodes[np.argsort(c.nodes[:, 0], kind="stable")]
@@ -402,7 +410,7 @@ class NativeSampler(Sampler):
                     self.swap_round()
         s = self.native.samples()
         out = []
-        for i in np.argsort(s["sweep"], kind="stable"):
+        for i in np.lexsort((s["chain"], s["sweep"])):  # the ring is filled through an atomic counter: order by (sweep, chain)
             k = int(s["k"][i])
             nodes = np.column_stack([s["z"][i, :k], s["v"][i, :k]])
             out.append((k, nodes[np.argsort(nodes[:, 0], kind="stable")], float(s["sd"][i]), float(s["logL"][i])))

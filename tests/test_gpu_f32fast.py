@@ -1,0 +1,157 @@
+"""The single-precision FAST forward model (rtmi_trace_device_f32_fast, csrc/rtmi_f32fast.hip; BASELINE.json configs[4]).
+
+It is not the reference's iteration, so there is no bit-equality to assert.  What is pinned instead:
+  * against a fully CONVERGED double-precision solution of the reference's own equations (costFunc
+    subroutineR-quiet.f90:184-202 = 0, travel-time sum :156-166, stack by whichLayer / InsertLayer) -- `converged_times`
+    below, numpy: max |dt| < 3e-6 s (single-precision roundoff of a ~3 s travel time);
+  * against the oracle (= the reference, which stops 0.1 m short of the root): median < 1e-6 s, 99.9 % < 1e-4 s -- the
+    reference's own stopping tolerance, 0.1 m / 1500 m/s = 6.7e-5 s at most -- with the tolerance written here;
+  * the reference's layer-selection quirks (a source exactly on an interface / on the LAST interface), the top layer, the
+    half-space, offset 0, low-velocity zones, 1 ... 63 interfaces, the preconditions (sorted interfaces, <= 63 of them)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def converged_times(v, d, off, dep):
+    """t(p*) with f(p*) = 0 to double-precision roundoff: monotone Newton in s = tan(theta) of the stack's fastest layer
+    (X(s) = s sum H r / sqrt(1 + c s^2) is concave increasing), sources grouped by layer.  Returns (t, p)."""
+    v, d, R, z = (np.asarray(a, np.float64) for a in (v, d, off, dep))
+    NL, n = d.size, R.size
+    cnt = np.searchsorted(d, z, side="right")
+    il = cnt.copy()
+    il[(cnt == NL) & (z == d[-1])] = NL - 1          # whichLayer's special case (:22-30)
+    t, p = np.empty(n), np.full(n, np.nan)
+    for L in range(NL + 1):
+        m = il == L
+        if not m.any():
+            continue
+        Rm, zm = R[m], z[m]
+        if L == 0:
+            t[m] = np.sqrt(zm * zm + Rm * Rm) / v[0]
+            continue
+        V = v[:L + 1]
+        vmax = V.max()
+        H = np.concatenate([[d[0]], np.diff(d[:L])])
+        c = (vmax - V) * (vmax + V) / (vmax * vmax)
+        hl = zm - d[L - 1]
+        A = np.concatenate([np.broadcast_to(H * V[:L] / vmax, (m.sum(), L)), (hl * V[L] / vmax)[:, None]], 1)
+        B = np.concatenate([np.broadcast_to(H / V[:L], (m.sum(), L)), (hl / V[L])[:, None]], 1)
+        s = Rm / A.sum(1)
+        for _ in range(60):
+            y = 1.0 / np.sqrt(1.0 + c[None, :] * (s * s)[:, None])
+            s = s + (Rm - s * (A * y).sum(1)) / (A * y ** 3).sum(1)
+        y = 1.0 / np.sqrt(1.0 + c[None, :] * (s * s)[:, None])
+        t[m] = np.sqrt(1.0 + s * s) * (B * y).sum(1)
+        p[m] = s / np.sqrt(1.0 + s * s) / vmax
+    return t, p
+
+
+def c5_model(nl=20, seed=2025):
+    rng = np.random.default_rng(seed)
+    return np.sort(rng.uniform(1500, 6500, nl + 1)), np.cumsum(rng.uniform(200, 600, nl))
+
+
+def run_fast(v, d, off, dep, want_p=False):
+    import torch
+    import raytracerfortran_amd as rt
+    rt.load_library(); rt.init(0)
+    dev = "cuda"
+    tv, td, to, tz = (torch.tensor(np.asarray(a, np.float32), device=dev) for a in (v, d, off, dep))
+    p = torch.empty(to.numel(), dtype=torch.float32, device=dev) if want_p else None
+    t = rt.trace_device(tv, td, to, tz, p_final=p, fast=True)
+    torch.cuda.synchronize()
+    assert rt.load_library().rtmi_device_status() == 0
+    return (t.cpu().numpy(), p.cpu().numpy()) if want_p else t.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_fast_path_config5_against_converged_solution_and_reference():
+    v, d = c5_model()
+    rng = np.random.default_rng(7)
+    n = 300_000
+    off, dep = rng.uniform(10, 8000, n), rng.uniform(50, d[-1] + 500, n)
+    # what the kernel sees is the float-rounded problem: both checkers get exactly those inputs
+    v32, d32, off32, dep32 = (np.asarray(a, np.float32).astype(np.float64) for a in (v, d, off, dep))
+    t, p = run_fast(v, d, off, dep, want_p=True)
+    tc, pc = converged_times(v32, d32, off32, dep32)
+    assert not (t == -999.0).any()
+    e = np.abs(t.astype(np.float64) - tc)
+    assert e.max() < 3e-6, e.max()                                   # single-precision roundoff of a travel time of seconds
+    ref = O.oracle_dff(v32, d32, off32, dep32)
+    ok = ref != -999.0
+    er = np.abs(t[ok].astype(np.float64) - ref[ok])
+    # the reference stops at |f| < 0.1 m: dt <= p dX <= 0.1 / 1500 = 6.7e-5 s where its iteration behaved; its rare
+    # accepted-but-unconverged iterates (the inverted test of solve, :327-330) are its own errors, not this kernel's
+    assert np.median(er) < 1e-6 and np.percentile(er, 99.9) < 1e-4, (np.median(er), np.percentile(er, 99.9))
+    # where the reference deviates grossly, the converged solution says who is right
+    gross = er > 1e-3
+    assert np.abs(t[ok][gross].astype(np.float64) - tc[ok][gross]).max(initial=0.0) < 3e-6
+    # the ray parameter solves the reference's equation
+    deep = ~np.isnan(pc)
+    assert np.isnan(p[~deep]).all()
+    assert np.abs(p[deep] / pc[deep] - 1.0).max() < 2e-6
+    print(f"f32 fast vs converged fp64: max {e.max():.2e} s; vs reference: median {np.median(er):.2e}, 99.9 % {np.percentile(er, 99.9):.2e}, "
+          f"max {er.max():.2e} s ({int(gross.sum())} sources where the reference is off by > 1 ms, {int((~ok).sum())} reference sentinels)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nl", [1, 2, 7, 31, 63])
+def test_fast_path_layer_selection_and_edge_sources(nl):
+    rng = np.random.default_rng(100 + nl)
+    d = np.cumsum(rng.uniform(150, 500, nl))
+    v = rng.uniform(1500, 7000, nl + 1)                              # unsorted velocities: low-velocity zones
+    d32 = d.astype(np.float32).astype(np.float64)
+    n = 20_000
+    off, dep = rng.uniform(0.5, 9000, n), rng.uniform(1.0, d[-1] + 800, n)
+    # sources exactly on interfaces (incl. the last one), at offset 0, just above / below interfaces
+    k = min(nl, 200)
+    dep[:k] = d32[rng.integers(0, nl, k)]
+    dep[k:2 * k] = d32[-1]
+    off[2 * k:2 * k + 50] = 0.0
+    dep[2 * k + 50:2 * k + 100] = np.nextafter(d32[rng.integers(0, nl, 50)].astype(np.float32), np.float32(0)).astype(np.float64)
+    v32, off32, dep32 = (np.asarray(a, np.float32).astype(np.float64) for a in (v, off, dep))
+    t = run_fast(v, d, off, dep)
+    tc, _ = converged_times(v32, d32, off32, dep32)
+    bad = t == -999.0
+    # a ray that does not exist: the fastest layer of the stack is the source's own and the source sits on its top
+    # (thickness 0), and the offset is beyond what the slower layers can cover -- the converged solution diverges there too
+    assert bad.mean() < 0.02
+    e = np.abs(t[~bad].astype(np.float64) - tc[~bad])
+    assert e.max() < 5e-6, (nl, e.max())
+    ref = O.oracle_dff(v32, d32, off32, dep32)
+    ok = (ref != -999.0) & ~bad
+    er = np.abs(t[ok].astype(np.float64) - ref[ok])
+    assert np.percentile(er, 99.0) < 1e-4, (nl, np.percentile(er, 99.0))
+
+
+@pytest.mark.gpu
+def test_fast_path_preconditions_and_determinism():
+    import torch
+    import raytracerfortran_amd as rt
+    rt.load_library(); rt.init(0)
+    lib = rt.load_library()
+    v, d = c5_model()
+    rng = np.random.default_rng(3)
+    n = 70_001                                                       # ragged: not a multiple of the tile
+    off, dep = rng.uniform(10, 8000, n), rng.uniform(50, d[-1] + 500, n)
+    a, b = run_fast(v, d, off, dep), run_fast(v, d, off, dep)
+    assert np.array_equal(a, b)                                      # the sort's atomics do not reach the results
+    assert run_fast(v, d, off[:0], dep[:0]).size == 0
+    # more than 63 interfaces: refused
+    v64, d64 = c5_model(64)
+    dev = "cuda"
+    with pytest.raises(rt.raymod.RtmiError):
+        rt.trace_device(*(torch.tensor(np.asarray(x, np.float32), device=dev) for x in (v64, d64, off, dep)), fast=True)
+    # unsorted interfaces / a non-positive velocity: NaN everywhere and fault bit 8
+    for vv, dd in ((v, d[::-1].copy()), (np.where(np.arange(v.size) == 3, -1.0, v), d)):
+        t = rt.trace_device(*(torch.tensor(np.asarray(x, np.float32), device=dev) for x in (vv, dd, off, dep)), fast=True)
+        torch.cuda.synchronize()
+        assert torch.isnan(t).all()
+        assert lib.rtmi_clear_device_status() == 8
+    # NaN / Inf source data: the sentinel, as the double-precision path
+    off2, dep2 = off[:256].copy(), dep[:256].copy()
+    off2[5], dep2[9], off2[11] = np.nan, np.nan, np.inf
+    t = run_fast(v, d, off2, dep2)
+    assert t[5] == -999.0 and t[9] == -999.0 and t[11] == -999.0 and (t[np.r_[0:5, 12:256]] > 0).all()

@@ -68,6 +68,44 @@ def test_tempering_helps_and_levels_stay_a_permutation():
     assert abs(vmean - 4000.0) < 300.0
 
 
+class NanForFastTopEvaluator:
+    """NaN residual sum for every model whose shallowest node is faster than 6000 m/s (NaN data / an unusable model row)."""
+    def __call__(self, node_sets):
+        out = []
+        for nodes in node_sets:
+            top = nodes[np.argsort(nodes[:, 0], kind="stable")][0, 1]
+            out.append(float("nan") if top > 6000.0 else 1.0)
+        return np.array(out)
+
+
+def test_nan_likelihood_is_minus_huge_and_never_accepted():
+    """loglhood.f90:197-200: a NaN logL becomes -HUGE(1._RP), so such a proposal loses against any finite current model
+    (a NaN left in place would be ACCEPTED by `not (u >= exp(NaN))` and would then stick)."""
+    assert T.gaussian_loglike(float("nan"), 20, 0.02) == -sys.float_info.max
+    assert not T.mh_accept(0.0, float("nan")) and T.mh_accept(0.5, 0.0) and not T.mh_accept(0.5, -50.0)
+    pr = T.Prior(kmin=1, kmax=4)
+    s = T.Sampler(pr, NanForFastTopEvaluator(), ndata=20, nchains_total=4, nptchains1=4, seed=9)
+    s.init_from_prior()
+    for c in s.chains:       # start every chain from a model with a finite likelihood
+        c.nodes = np.array([[0.0, 3000.0]])
+    s._evaluate_current()
+    s.run(300)
+    for c in s.chains:
+        assert math.isfinite(c.logL) and c.logL > -1e300
+        assert c.nodes[np.argsort(c.nodes[:, 0], kind="stable")][0, 1] <= 6000.0
+
+
+def test_samples_are_recorded_after_every_thin_th_sweep():
+    """prjmh_temper_rf.f90:329-389: DO ithin = 1, ICHAINTHIN ... SAVESAMPLE -- the sample is taken AFTER thin sweeps,
+    floor((nsweeps - burnin) / thin) samples per T = 1 chain (the device sampler's rule, NativeSampler.run)."""
+    pr = T.Prior(kmin=1, kmax=3)
+    s = T.Sampler(pr, FlatEvaluator(), ndata=20, nchains_total=2, nptchains1=2, seed=4)
+    s.init_from_prior()
+    assert len(s.run(10, burnin=1, thin=3)) == 2 * 3      # sweeps 4, 7, 10 (1-based) of the 9 after the burn-in
+    assert len(s.run(5, burnin=0, thin=5)) == 2 * 1
+    assert len(s.run(4, burnin=0, thin=5)) == 0
+
+
 def _pt_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -566,3 +604,75 @@ def test_sampler_sums_are_exact_hence_independent_of_the_launch_geometry():
     v, d = T.layering(nodes)
     want = O.oracle_loglhood_rt(obs, O.oracle_dff(v, d, off, dep), 0.016, stable=True)
     assert abs(ref[0] - want) <= 1e-11 * abs(want)
+
+
+@pytest.mark.gpu
+def test_incremental_likelihood_when_the_first_node_is_not_the_shallowest():
+    """The residual cache assumes nothing about node 0: a chain set up with its first node below the surface, or with
+    another node above it, changes its TOP layer when the shallowest node's velocity moves or when a node becomes the
+    shallowest -- every source is affected then, whatever that node's depth.  Chains, statistics and ladder must be those
+    of the full evaluation (RTMI_PT_INCREMENTAL=0), bit for bit."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod, synthetic as S
+    n, nch = 10_000, 16
+    off, dep = S.sampler_sources(n, 6)
+    rt.load_library(); rt.init(0)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"] + np.random.default_rng(5).normal(0, 0.016, n)
+    rt.set_sources(off, dep, obs)
+    base = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    deep_first = base.copy()
+    deep_first[0, 0] = 1500.0                      # node 0 sits at 1500 m: the node of rank 0 is another one
+    lifted = base.copy()
+    lifted[0, 0] = 700.0                           # node 0 is the shallowest, but not at the surface
+    out = {}
+    old_inc, old_p = os.environ.get("RTMI_PT_INCREMENTAL"), os.environ.get("RTMI_PT_PERSISTENT")
+    try:
+        os.environ["RTMI_PT_PERSISTENT"] = "0"
+        for inc in ("0", "1"):
+            os.environ["RTMI_PT_INCREMENTAL"] = inc
+            h = raymod.NativeChains(nch, 11, n, T.Prior(), seed=33)
+            for i in range(nch):
+                h.set_chain(i, (deep_first, lifted, base)[i % 3], 0.016, 1.0)
+            h.evaluate()
+            h.set_ladder(nch, 0, np.arange(nch) // 2, 1.15 ** -np.arange(8.0))
+            h.run(40, 1, None, 0)
+            out[inc] = (h.get_all(), h.stats(), h.get_ladder()[0], h.likelihood_counts())
+            del h
+    finally:
+        for name, val in (("RTMI_PT_INCREMENTAL", old_inc), ("RTMI_PT_PERSISTENT", old_p)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+    (a0, s0, l0, c0), (a1, s1, l1, c1) = out["0"], out["1"]
+    for key in ("k", "sd", "logL", "ss", "beta"):
+        assert np.array_equal(a0[key], a1[key]), key
+    live = np.arange(a0["z"].shape[1])[None, :] < a0["k"][:, None]
+    assert np.array_equal(a0["z"][live], a1["z"][live]) and np.array_equal(a0["v"][live], a1["v"][live])
+    assert np.array_equal(l0, l1) and s0 == s1
+    assert c0 == (0, 0) and c1[1] > 0              # the cache was off / was used
+    assert s0["acc_mh"] > 0
+    assert rt.load_library().rtmi_device_status() == 0
+
+
+@pytest.mark.gpu
+def test_device_sampler_maps_a_nan_likelihood_to_minus_huge():
+    """One NaN observation makes every sum of squared residuals NaN: the device step must hold logL = -HUGE (the
+    reference's rule, loglhood.f90:197-200), not NaN -- a NaN would be accepted and then stick."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod, synthetic as S
+    n, nch = 4096, 8
+    off, dep = S.sampler_sources(n, 6)
+    rt.load_library(); rt.init(0)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"].copy()
+    obs[17] = np.nan
+    rt.set_sources(off, dep, obs)
+    h = raymod.NativeChains(nch, 11, n, T.Prior(), seed=2)
+    nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    for i in range(nch):
+        h.set_chain(i, nodes, 0.016, 1.0)
+    h.evaluate()
+    h.run(10, 0, None, 0)
+    a = h.get_all()
+    assert np.all(a["logL"] == -sys.float_info.max), a["logL"]
+    assert rt.load_library().rtmi_device_status() == 0
