@@ -319,6 +319,73 @@ def bench_c4(args, rt, torch, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bench_c5(args, rt, torch, dist, rank, world, dev):
+    """BASELINE config 5 (fp32 kernel path: 1e7 sources x 20 interfaces over 8 GPUs, delta-t vs fp64 reported) as a
+    driver-runnable number: every rank traces its own 1.25e6-source shard (1e7 / 8; weak scaling, no collective) of the
+    20-interface model with the single-precision FAST forward model (rtmi_trace_device_f32_fast); the line also carries the
+    fp32 path that repeats the reference's iteration in float, the fp64 path on the same (float-rounded) inputs, and the
+    deviation of both fp32 paths from the fp64 result."""
+    n = 1_250_000 if args.nsrc == 1_000_000 else args.nsrc
+    rng = np.random.default_rng(2025)
+    d = np.cumsum(rng.uniform(200, 600, 20))
+    v = np.sort(rng.uniform(1500, 6500, 21))
+    rng = np.random.default_rng([2025, rank])
+    off, dep = rng.uniform(10, 8000, n), rng.uniform(50, d[-1] + 500, n)
+    f32 = [torch.tensor(np.asarray(a, np.float32), device=dev) for a in (v, d, off, dep)]
+    f64 = [t.double() for t in f32]
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rt.trace_device(*f32, timeP=out, stream=stream, fast=True)
+
+    elapsed, kern_ms = timed_steps(step, args.steps, args.warmup, world, dist if world > 1 else None, dev,
+                                   sync=torch.cuda.synchronize,
+                                   make_event=lambda: torch.cuda.Event(enable_timing=True), stream=stream)
+    if rank == 0:
+        def ms_of(fn, reps=10):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, r
+        ms64, t64 = ms_of(lambda: rt.trace_device(*f64))
+        ms32, t32 = ms_of(lambda: rt.trace_device(*f32))
+        t64 = t64.cpu().numpy()
+
+        def dev_of(t):
+            t = t.cpu().numpy().astype(np.float64)
+            both = (t64 != -999.0) & (t != -999.0)
+            e = np.abs(t[both] - t64[both])
+            return {"median_s": float(np.median(e)), "p999_s": float(np.percentile(e, 99.9)), "max_s": float(e.max()),
+                    "sentinels": int((t == -999.0).sum())}
+        value = world * n * args.steps / elapsed
+        algo = 12.0 * n
+        achieved = algo / (kern_ms * 1e-3) / 1e9
+        res = {"metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "ranks": world, "devices": args.devices, "collective_backend": args.backend,
+               "config": {"workload": "C5: fp32 fast forward model, %d sources per GPU x 20 interfaces (1e7 over 8 GPUs), seed 2025; "
+                                      "BASELINE.json configs[4]" % n,
+                          "nsrc_per_gpu": n, "nlayers": 20, "sharding": "sources per rank, no collective"},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                            "kernel": "rtmi::f32fast_kernel", "algorithmic_bytes_per_launch": algo,
+                            "note": "12 B per travel time; fp32-VALU-bound (about 900 instructions per 64 sources), DESIGN.md section 4.3"},
+               "delta_t_vs_fp64": {"fp32_fast": dev_of(out), "fp32_reference_iteration": dev_of(t32),
+                                   "fp64_sentinels": int((t64 == -999.0).sum()),
+                                   "note": "same float-rounded inputs; the reference stops 0.1 m short of the root (up to 6.7e-5 s), "
+                                           "the fast path solves to single-precision roundoff (1e-6 s of the converged solution)"},
+               "other_paths": {"fp64_ms": ms64, "fp64_travel_times_per_s": n / ms64 * 1e3,
+                               "fp32_reference_iteration_ms": ms32, "fp32_reference_iteration_travel_times_per_s": n / ms32 * 1e3}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_pt(args, rt, torch, dist, rank, world, dev):
     """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, device-resident sweep csrc/rtmi_pt.hip): 32 chains per GPU over 1e4 shared sources
     (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
@@ -403,10 +470,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive drop-in figures (c2 only)")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
-    ap.add_argument("--workload", choices=["c2", "pt", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "pt", "c4", "c5"], default="c2",
                     help="c2: single dff forward, 1e6 sources (the bench metric's configuration, default); "
                          "pt: parallel-tempering sweeps, 32 chains per GPU x 1e4 sources (BASELINE config 3 shape); "
-                         "c4: batched likelihood of config 4's per-GPU share, 32 models (k in [2,30]) x 1e5 sources")
+                         "c4: batched likelihood of config 4's per-GPU share, 32 models (k in [2,30]) x 1e5 sources; "
+                         "c5: fp32 fast forward model, 1.25e6 sources per GPU x 20 interfaces (config 5's share), with the "
+                         "deviation from fp64")
     ap.add_argument("--path", choices=["auto", "plain", "fused"], default="auto",
                     help="kernel path of rtmi_trace_device (A/B runs; auto = what the library picks)")
     return ap.parse_args(argv)
@@ -456,6 +525,8 @@ def main():
         return bench_pt(args, rt, torch, dist, rank, world, dev)
     if args.workload == "c4":
         return bench_c4(args, rt, torch, dist, rank, world, dev)
+    if args.workload == "c5":
+        return bench_c5(args, rt, torch, dist, rank, world, dev)
 
     n = args.nsrc
     v, d, off, dep = c2_workload(n, shard=rank)

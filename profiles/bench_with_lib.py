@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 from raytracerfortran_amd import raymod
 raymod.LIB_PATH = os.path.abspath(sys.argv[1])
 import ctypes
+import torch  # noqa: F401  (first: one HIP runtime per process, see raymod.load_library)
 _probe = ctypes.CDLL(raymod.LIB_PATH)   # an older build may lack newer entry points: they are not what is being measured
 for _name in [n for n in raymod.SIGNATURES if not hasattr(_probe, n)]:
     del raymod.SIGNATURES[_name]

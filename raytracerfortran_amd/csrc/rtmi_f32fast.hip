@@ -18,7 +18,7 @@
 // reference (which stops 0.1 m short of the root): median 2.4e-7 s, 99.9th percentile 3.4e-5 s = the reference's own
 // stopping tolerance (tests/test_gpu_f32fast.py).
 //
-// Machine mapping: persistent workgroups of 256 lanes; per tile of 2048 sources a counting sort by source layer in LDS (so
+// Machine mapping: persistent workgroups of 256 lanes; per tile of 1024 sources a counting sort by source layer in LDS (so
 // that the 64 lanes of a wave walk the same number of layers), one source per lane, the per-stack coefficient rows
 // {c, H r, H / V} as 16-byte LDS entries (one ds_read_b128 per layer, broadcast when the wave shares a row), v_rsq_f32 for
 // every 1 / sqrt, results returned to input order through LDS so that the stores are coalesced.  12 B of HBM per source.
@@ -32,7 +32,9 @@
 namespace rtmi {
 
 #define F32F_BLOCK 256
-#define F32F_PER_THREAD 8
+#ifndef F32F_PER_THREAD
+#define F32F_PER_THREAD 4  // tiles of 1024 sources: four workgroups (16 waves) per CU; tiles of 2048 (three workgroups) were 12 % slower
+#endif
 #define F32F_TILE (F32F_BLOCK * F32F_PER_THREAD)
 #define F32F_MAXIT 12
 
@@ -42,7 +44,9 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     const int NL = a.nlayers, W = NL + 1;  // source layers il = 0 .. NL, rows of W entries
     float4 *tab = reinterpret_cast<float4 *>(lds_raw);           // [W][W] tab[il * W + i] = {c_i, H_i r_i, H_i / V_i, 0}, i < il; zeros from i = il on
     float4 *diag = tab + (size_t)W * W;                          // [W] the source's own layer: {c_l, r_l, 1 / V_l, sum_{i < il} H_i r_i}
-    float *vmi = reinterpret_cast<float *>(diag + W);            // [W] 1 / vmax of the stack
+    float4 *diag2 = diag + W;                                    // [W] {sum of H r over the stack's fastest full layers, sum of H r / sqrt(c)
+                                                                 //      over its slower ones, 1 / sqrt(c_l) (0 if the own layer is a fastest one), 0}
+    float *vmi = reinterpret_cast<float *>(diag2 + W);           // [W] 1 / vmax of the stack
     float *D = vmi + W;                                          // [NL] interface depths
     float *sz = D + ((NL + 3) & ~3);                             // [TILE] depth, sorted by layer
     float *sR = sz + F32F_TILE;                                  // [TILE] offset
@@ -96,12 +100,21 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     }
     for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
         const double vm = vmaxd[il], vl = (double)a.d_vels[il];
-        double afull = 0.0;
+        double afull = 0.0, hc = 0.0, binf = 0.0;
         for (int i = 0; i < il; ++i) {
             const double h = i == 0 ? (double)a.d_depths[0] : (double)a.d_depths[i] - (double)a.d_depths[i - 1];
-            afull += h * ((double)a.d_vels[i] / vm);
+            const double vi = (double)a.d_vels[i], ai = h * (vi / vm);
+            const float ci = (float)((vm - vi) * (vm + vi) / (vm * vm));  // as tabulated
+            afull += ai;
+            if (ci > 0.0f)
+                binf += ai / sqrt((double)ci);
+            else
+                hc += ai;
         }
-        diag[il] = make_float4((float)((vm - vl) * (vm + vl) / (vm * vm)), (float)(vl / vm), (float)(1.0 / vl), (float)afull);
+        const float cl = (float)((vm - vl) * (vm + vl) / (vm * vm));
+        diag[il] = make_float4(cl, (float)(vl / vm), (float)(1.0 / vl), (float)afull);
+        // rounded so that the start value stays a LOWER bound of the root: hc up, the saturated offset up
+        diag2[il] = make_float4((float)(hc * (1.0 + 1e-6)), (float)(binf * (1.0 + 1e-6)), cl > 0.0f ? (float)(1.0 / sqrt((double)cl)) : 0.0f, 0.0f);
     }
     __syncthreads();
 
@@ -187,7 +200,14 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 const float hl = zq - D[ile - 1];
                 const float cl = dg.x, al = hl * dg.y, bl = hl * dg.z;
                 const float4 *row = tab + (size_t)ile * W;
-                float s = Rq * __builtin_amdgcn_rcpf(dg.w + al);  // lower bound of the root: X(s) <= s sum H_i r_i
+                // two lower bounds of the root: X(s) <= s sum H_i r_i, and X(s) <= hc s + B with hc the fastest layers' share
+                // and B what the slower layers can cover at most (s -> infinity): the second one starts a near-critical ray,
+                // the kind that would otherwise climb for ten iterations, next to its root
+                const float4 d2 = diag2[ile];
+                const float hcq = d2.x + (cl > 0.0f ? 0.0f : al), bq = d2.y + al * d2.z;
+                float s = Rq * __builtin_amdgcn_rcpf(dg.w + al);
+                if (hcq > 0.0f)
+                    s = fmaxf(s, (Rq - bq) * __builtin_amdgcn_rcpf(hcq) * 0.999999f);
                 bool conv = !valid || ilq == 0;
                 for (int it = 0; it < F32F_MAXIT && __any(!conv); ++it) {
                     const float ss = s * s;
@@ -207,7 +227,9 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                     }
                     const float ds = (Rq - s * S1) * __builtin_amdgcn_rcpf(S3);
                     const float sn = s + ds;
-                    const bool now = !(__builtin_fabsf(ds) > 3e-7f * sn);  // also true for NaN: such a lane stops here
+                    // the iterates climb (X is concave: a Newton step from the left stays left of the root), so a step that
+                    // is not a climb of more than 1e-6 s any more is the roundoff floor; also true for NaN: such a lane stops
+                    const bool now = !(ds > 1e-6f * sn) && !(ds < -1e-4f * s);  // (a step back that is no roundoff: go on)
                     s = conv ? s : sn;  // a converged lane is frozen: its result does not depend on its neighbours
                     conv = conv || now;
                 }
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 extern "C" size_t rtmi_f32fast_lds_bytes(int nlayers)
 {
     const size_t W = (size_t)nlayers + 1;
-    size_t b = W * W * sizeof(float4) + W * sizeof(float4) + W * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
+    size_t b = W * W * sizeof(float4) + 2 * W * sizeof(float4) + W * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
     b += (size_t)4 * F32F_TILE * sizeof(float);                 // sz, sR, tout, pout
     b += ((W + 3) & ~(size_t)3) * sizeof(uint32_t);             // hist
     b += (size_t)F32F_TILE * sizeof(uint32_t);                  // sidx

@@ -209,7 +209,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 }
 
 #ifndef RTMI_PREFETCH
-#define RTMI_PREFETCH 1      // chunks of source data a wave keeps in flight in the load / sort passes
+#define RTMI_PREFETCH 4      // chunks of source data a wave keeps in flight in the load / sort passes
 #endif
 #define RTMI_RK_LOC_MASK 0x1FFFu      // rk: local source index within the workgroup's round (< 8192)
 #define RTMI_RK_NL_SHIFT 13           // rk: nl in bits 13..23 (nl <= 1025)
@@ -277,13 +277,18 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         const int64_t k = chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
-    // a window of RTMI_PREFETCH chunks per wave is kept in flight (C2: a wave's four chunks of the round, all at once)
-    T zw[RTMI_PREFETCH], Rw[RTMI_PREFETCH];
+    // a window of PF chunks per wave is kept in flight (C2: a wave's four chunks of the round, all at once; the forms of the
+    // kernel with residual sums are at their register limit and keep two)
+    constexpr int PF = INC ? 1 : (WANT_SS ? 2 : RTMI_PREFETCH);
+    T zw[PF], Rw[PF];
 #pragma unroll
-    for (int j = 0; j < RTMI_PREFETCH; ++j)
+    for (int j = 0; j < PF; ++j)
         zw[j] = depth_of(0, wib + j * nwib);
     const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS, a.skiptab != 0);
-    stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
+    // DET: the records' slots decide the order of the floating-point residual sum (the batch API's logL), so the sort must
+    // be the same on every run: ranks by ballots.  Every other form of the kernel (travel times only; the sampler's
+    // order-independent sums) is indifferent to WHICH slot of its bin a record gets: ranks by one LDS atomic per lane.
+    constexpr bool DET = WANT_SS && !INC;
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
     T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
@@ -312,6 +317,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // live in `hist`, which is free once the records are in their slots
     unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [128]
     unsigned long long *ch_start = ch_cnt + 128;                                  // [128]
+    if constexpr (!DET) {
+        if (threadIdx.x < 64)
+            hist[threadIdx.x] = 0u;  // the bin counters of the first round: zeroed before the barriers of stage_model
+    }
+    stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
 
     const int64_t b = bx;
     const int64_t nblocks = gx;
@@ -334,20 +344,20 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         uint32_t mycnt = 0;
         if (j0 > 0) {
 #pragma unroll
-            for (int j = 0; j < RTMI_PREFETCH; ++j)
+            for (int j = 0; j < PF; ++j)
                 zw[j] = depth_of(j0, wib + j * nwib);
+            if constexpr (!DET) {
+                if (threadIdx.x < 64)
+                    hist[threadIdx.x] = 0u;  // (the round before ended with a barrier; nothing has touched hist since)
+                __syncthreads();
+            }
         }
-        for (int c = wib; c < CH; c += nwib) {
-            const int64_t chunk = b + (j0 + c) * nblocks;
-            if (chunk >= nchunks)
-                break;
+        // The window of PF chunks is indexed statically (the loop over a wave's chunks is unrolled by the window):
+        // a chunk's registers are reloaded for the chunk PF steps ahead as soon as they are consumed, and no
+        // register is moved -- a move would make the compiler wait for every load in flight.
+        auto pass1 = [&](const int c, const int64_t chunk, const T z) {
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const T z = zw[0];
-#pragma unroll
-            for (int j = 0; j + 1 < RTMI_PREFETCH; ++j)
-                zw[j] = zw[j + 1];
-            zw[RTMI_PREFETCH - 1] = depth_of(j0, c + RTMI_PREFETCH * nwib);
             // incremental likelihood: a source the proposal does not affect is neither located nor sorted (its squared
             // residual is added from the cache in the second pass)
             const bool unaffected = inc && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
@@ -355,8 +365,12 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             if (!valid)
                 nl = 1;  // like a straight ray: never queued
             const int bin = bin_of(nl, nl_max);
-            uint32_t rank = 0;  // of this record among the wave's records of its bin (chunks in order, lanes in order)
-            unsigned long long todo = __ballot(nl > 1);
+            uint32_t rank = 0;  // DET: of this record among the wave's records of its bin (chunks in order, lanes in order)
+            if constexpr (!DET) {
+                if (nl > 1)
+                    rank = atomicAdd(&hist[bin], 1u);  // of this record among the workgroup's records of its bin, in no particular order
+            }
+            unsigned long long todo = DET ? __ballot(nl > 1) : 0ull;
             while (todo) {
                 const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
                 const unsigned long long grp = __ballot(nl > 1 && bin == lb);
@@ -368,10 +382,24 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 todo &= ~grp;
             }
             tnl[c * 64 + lane] = (uint32_t)nl | (rank << 11);  // nl <= 1025, rank < 8192
-        }
-        hist[wib * 64 + lane] = mycnt;
+        };
+#pragma unroll 1
+        for (int cb = wib; cb < CH; cb += PF * nwib) {
 #pragma unroll
-        for (int j = 0; j < RTMI_PREFETCH; ++j) {  // in flight during the scan
+            for (int j = 0; j < PF; ++j) {
+                const int c = cb + j * nwib;
+                const int64_t chunk = b + (j0 + c) * nblocks;
+                if (c < CH && chunk < nchunks) {  // wave-uniform
+                    const T z = zw[j];
+                    zw[j] = depth_of(j0, c + PF * nwib);
+                    pass1(c, chunk, z);
+                }
+            }
+        }
+        if constexpr (DET)
+            hist[wib * 64 + lane] = mycnt;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {  // in flight during the scan
             Rw[j] = offset_of(j0, wib + j * nwib);
             zw[j] = depth_of(j0, wib + j * nwib);
         }
@@ -380,8 +408,12 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             stamps[4] = clock64();  // depths loaded, bins counted
         if (wib == 0) {
             uint32_t tot = 0;
-            for (int w = 0; w < nwib; ++w)
-                tot += hist[w * 64 + lane];
+            if constexpr (DET) {
+                for (int w = 0; w < nwib; ++w)
+                    tot += hist[w * 64 + lane];
+            } else {
+                tot = hist[lane];
+            }
             uint32_t incl = tot;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -391,10 +423,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             }
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t run = total - incl;  // first slot of bin `lane` when bins are laid out descending
-            for (int w = 0; w < nwib; ++w) {
-                const uint32_t c = hist[w * 64 + lane];
-                hist[w * 64 + lane] = run;  // first slot of (wave w, bin lane)
-                run += c;
+            if constexpr (DET) {
+                for (int w = 0; w < nwib; ++w) {
+                    const uint32_t c = hist[w * 64 + lane];
+                    hist[w * 64 + lane] = run;  // first slot of (wave w, bin lane)
+                    run += c;
+                }
+            } else {
+                hist[lane] = run;               // first slot of bin lane
             }
             if (lane == 0) {
                 qctl[0] = 0;
@@ -409,24 +445,13 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 pl_ready[i] = 0;
         }
         __syncthreads();
-        for (int c = wib; c < CH; c += nwib) {
-            const int64_t chunk = b + (j0 + c) * nblocks;
-            if (chunk >= nchunks)
-                break;
+        auto pass2 = [&](const int c, const int64_t chunk, const T R, const T z) {
             const int64_t k = chunk * 64 + lane;
             const bool valid = k < a.nsrc;
-            const T R = Rw[0], z = zw[0];
-#pragma unroll
-            for (int j = 0; j + 1 < RTMI_PREFETCH; ++j) {
-                Rw[j] = Rw[j + 1];
-                zw[j] = zw[j + 1];
-            }
-            Rw[RTMI_PREFETCH - 1] = offset_of(j0, c + RTMI_PREFETCH * nwib);
-            zw[RTMI_PREFETCH - 1] = depth_of(j0, c + RTMI_PREFETCH * nwib);
             const uint32_t packed = valid ? tnl[c * 64 + lane] : 1u;
             const int nl = (int)(packed & 0x7FFu);
             // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
-            const uint32_t pos = hist[wib * 64 + bin_of(nl, nl_max)] + (packed >> 11);
+            const uint32_t pos = hist[(DET ? wib * 64 : 0) + bin_of(nl, nl_max)] + (packed >> 11);
             // (incremental likelihood) not affected by the proposal, as in the first pass; counted per wave
             const bool cached = inc && valid && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
             if (inc) {
@@ -467,10 +492,24 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                         }
                     }
                 } else {
+                    // (the start value p0 is computed by the first-evaluation pass, from the record)
                     rR[pos] = R;
                     rz[pos] = z;
-                    rp[pos] = initial_p0(t, nl - 1, R, z);
                     rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
+                }
+            }
+        };
+#pragma unroll 1
+        for (int cb = wib; cb < CH; cb += PF * nwib) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int c = cb + j * nwib;
+                const int64_t chunk = b + (j0 + c) * nblocks;
+                if (c < CH && chunk < nchunks) {  // wave-uniform
+                    const T R = Rw[j], z = zw[j];
+                    Rw[j] = offset_of(j0, c + PF * nwib);
+                    zw[j] = depth_of(j0, c + PF * nwib);
+                    pass2(c, chunk, R, z);
                 }
             }
         }
@@ -491,8 +530,9 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             Lane<T> s;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
             const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
-            const T p0 = valid ? rp[q] : T(0.0);
-            lane_setup(s, t, nl - 1, valid ? rR[q] : T(1.0), valid ? rz[q] : T(1.0));
+            const T Rq = valid ? rR[q] : T(1.0), zq = valid ? rz[q] : T(1.0);
+            const T p0 = initial_p0(t, nl - 1, Rq, zq, valid);  // GetPTime's head (:112-133)
+            lane_setup(s, t, nl - 1, Rq, zq);
             lane_start(s, p0);
             const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
             if (!live)
