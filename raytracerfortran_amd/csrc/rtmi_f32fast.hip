@@ -41,9 +41,10 @@ namespace rtmi {
 __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int NL = a.nlayers, W = NL + 1;  // source layers il = 0 .. NL, rows of W entries
-    float4 *tab = reinterpret_cast<float4 *>(lds_raw);           // [W][W] tab[il * W + i] = {c_i, H_i r_i, H_i / V_i, 0}, i < il; zeros from i = il on
-    float4 *diag = tab + (size_t)W * W;                          // [W] the source's own layer: {c_l, r_l, 1 / V_l, sum_{i < il} H_i r_i}
+    const int NL = a.nlayers, W = NL + 1;  // source layers il = 0 .. NL
+    const int WS = (W + 3) & ~3;           // row stride: the layer loops run four entries at a time over zero-padded rows
+    float4 *tab = reinterpret_cast<float4 *>(lds_raw);           // [W][WS] tab[il * WS + i] = {c_i, H_i r_i, H_i / V_i, 0}, i < il; zeros from i = il on
+    float4 *diag = tab + (size_t)W * WS;                         // [W] the source's own layer: {c_l, r_l, 1 / V_l, sum_{i < il} H_i r_i}
     float4 *diag2 = diag + W;                                    // [W] {sum of H r over the stack's fastest full layers, sum of H r / sqrt(c)
                                                                  //      over its slower ones, 1 / sqrt(c_l) (0 if the own layer is a fastest one), 0}
     float *vmi = reinterpret_cast<float *>(diag2 + W);           // [W] 1 / vmax of the stack
@@ -56,23 +57,20 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     uint32_t *sidx = hist + ((W + 3) & ~3);                           // [TILE] local index | layer << 16 of the sorted record
     double *vmaxd = reinterpret_cast<double *>(sidx + F32F_TILE);      // [W] running maximum of the velocities (staging)
 
-    // ---- the model's tables (once per workgroup) ------------------------------------------------------------------
-    for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
-        double m = (double)a.d_vels[0];
-        for (int i = 1; i <= il; ++i)
-            m = fmax(m, (double)a.d_vels[i]);
-        vmaxd[il] = m;
-        vmi[il] = (float)(1.0 / m);
-    }
+    // ---- the model's tables (once per workgroup; the model itself goes through LDS: one round trip to memory) ---------------
+    float *Vs = tout;  // [W] velocities, staged in the results area (free until the first tile)
+    for (int i = threadIdx.x; i < W; i += F32F_BLOCK)
+        Vs[i] = a.d_vels[i];
     for (int i = threadIdx.x; i < NL; i += F32F_BLOCK)
         D[i] = a.d_depths[i];
+    __syncthreads();
     // this mode's precondition: interfaces in non-decreasing order from a non-negative depth, positive finite velocities
     bool bad = false;
     for (int i = threadIdx.x; i < W; i += F32F_BLOCK) {
-        const float v = a.d_vels[i];
+        const float v = Vs[i];
         bad = bad || !(v > 0.0f) || !(v < 3.0e38f);
         if (i < NL) {
-            const float d = a.d_depths[i], dp = i > 0 ? a.d_depths[i - 1] : 0.0f;
+            const float d = D[i], dp = i > 0 ? D[i - 1] : 0.0f;
             bad = bad || !(d >= dp) || !(d < 3.0e38f);
         }
     }
@@ -86,12 +84,20 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
         }
         return;
     }
-    for (int e = threadIdx.x; e < W * W; e += F32F_BLOCK) {
-        const int il = e / W, i = e - il * W;
+    for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
+        double m = (double)Vs[0];
+        for (int i = 1; i <= il; ++i)
+            m = fmax(m, (double)Vs[i]);
+        vmaxd[il] = m;
+        vmi[il] = (float)(1.0 / m);
+    }
+    __syncthreads();
+    auto thick = [&](int i) { return i == 0 ? (double)D[0] : (double)D[i] - (double)D[i - 1]; };
+    for (int e = threadIdx.x; e < W * WS; e += F32F_BLOCK) {
+        const int il = e / WS, i = e - il * WS;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (i < il) {
-            const double vm = vmaxd[il], vi = (double)a.d_vels[i];
-            const double h = i == 0 ? (double)a.d_depths[0] : (double)a.d_depths[i] - (double)a.d_depths[i - 1];
+            const double vm = vmaxd[il], vi = (double)Vs[i], h = thick(i);
             v.x = (float)((vm - vi) * (vm + vi) / (vm * vm));
             v.y = (float)(h * (vi / vm));
             v.z = (float)(h / vi);
@@ -99,11 +105,10 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
         tab[e] = v;
     }
     for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
-        const double vm = vmaxd[il], vl = (double)a.d_vels[il];
+        const double vm = vmaxd[il], vl = (double)Vs[il];
         double afull = 0.0, hc = 0.0, binf = 0.0;
         for (int i = 0; i < il; ++i) {
-            const double h = i == 0 ? (double)a.d_depths[0] : (double)a.d_depths[i] - (double)a.d_depths[i - 1];
-            const double vi = (double)a.d_vels[i], ai = h * (vi / vm);
+            const double vi = (double)Vs[i], ai = thick(i) * (vi / vm);
             const float ci = (float)((vm - vi) * (vm + vi) / (vm * vm));  // as tabulated
             afull += ai;
             if (ci > 0.0f)
@@ -136,17 +141,25 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
             z[j] = valid ? a.d_src_depth[k] : 0.0f;
             R[j] = valid ? a.d_src_offset[k] : 0.0f;
         }
+        // whichLayer (:9-32): 1-based index of the first interface strictly below z; NL + 1 below the last one; NL when z sits
+        // exactly on the last interface (neither > nor <).  With sorted interfaces (this mode's precondition, checked above)
+        // that index is 1 + the number of interfaces <= z.  il = index - 1: the source's layer.
+        int cnt[F32F_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < F32F_PER_THREAD; ++j)
+            cnt[j] = 0;
+        for (int i = 0; i < NL; ++i) {
+            const float di = D[i];  // one (broadcast) LDS read serves the thread's sources
+#pragma unroll
+            for (int j = 0; j < F32F_PER_THREAD; ++j)
+                cnt[j] += di <= z[j] ? 1 : 0;
+        }
+        const float dlast = D[NL - 1];
 #pragma unroll
         for (int j = 0; j < F32F_PER_THREAD; ++j) {
-            // whichLayer (:9-32): 1-based index of the first interface strictly below z; NL + 1 below the last one; NL when
-            // z sits exactly on the last interface (neither > nor <).  With sorted interfaces (this mode's precondition, checked
-            // by the launcher's caller) that index is 1 + the number of interfaces <= z.  il = index - 1: the source's layer.
-            int cnt = 0;
-            for (int i = 0; i < NL; ++i)
-                cnt += D[i] <= z[j] ? 1 : 0;
-            int nl = cnt + 1;
-            if (cnt == NL)
-                nl = (D[NL - 1] - z[j] < 0.0f) ? NL + 1 : NL;
+            int nl = cnt[j] + 1;
+            if (cnt[j] == NL)
+                nl = (dlast - z[j] < 0.0f) ? NL + 1 : NL;
             if (!(z[j] == z[j]))
                 nl = NL;  // NaN depth: every comparison of the reference is false
             il[j] = nl - 1;
@@ -188,10 +201,11 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
             const uint32_t rec = valid ? sidx[q] : 0u;
             const int ilq = (int)(rec >> 16);  // the record's layer
             float tt, pp = __builtin_nanf("");
-            int ilw = ilq;
+            int ilv = ilq;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
-                ilw = max(ilw, __shfl_xor(ilw, off, 64));
+                ilv = max(ilv, __shfl_xor(ilv, off, 64));
+            const int ilw = __builtin_amdgcn_readfirstlane(ilv);  // the wave's deepest stack, as a scalar
             if (ilw == 0) {
                 tt = __builtin_sqrtf(zq * zq + Rq * Rq) * diag[0].z;  // top layer (:94-97): t = sqrt(z^2 + R^2) / v_1
             } else {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 const float4 dg = diag[ile];
                 const float hl = zq - D[ile - 1];
                 const float cl = dg.x, al = hl * dg.y, bl = hl * dg.z;
-                const float4 *row = tab + (size_t)ile * W;
+                const float4 *row = tab + (size_t)ile * WS;
                 // two lower bounds of the root: X(s) <= s sum H_i r_i, and X(s) <= hc s + B with hc the fastest layers' share
                 // and B what the slower layers can cover at most (s -> infinity): the second one starts a near-critical ray,
                 // the kind that would otherwise climb for ten iterations, next to its root
@@ -212,12 +226,15 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 for (int it = 0; it < F32F_MAXIT && __any(!conv); ++it) {
                     const float ss = s * s;
                     float S1 = 0.0f, S3 = 0.0f;
-                    for (int i = 0; i < ilw; ++i) {
-                        const float4 e = row[i];  // zeros past the lane's own stack
-                        const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
-                        const float ty = e.y * y;
-                        S1 += ty;
-                        S3 = __builtin_fmaf(ty * y, y, S3);
+                    for (int i = 0; i < ilw; i += 4) {  // ilw is a scalar: no lane is masked, rows are zero past the lane's own stack
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float2 e = *reinterpret_cast<const float2 *>(row + i + u);  // {c, H r}
+                            const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
+                            const float ty = e.y * y;
+                            S1 += ty;
+                            S3 = __builtin_fmaf(ty * y, y, S3);
+                        }
                     }
                     {
                         const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(cl, ss, 1.0f));
@@ -235,11 +252,14 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 }
                 const float ss = s * s;
                 float S1 = 0.0f, SB = 0.0f;
-                for (int i = 0; i < ilw; ++i) {
-                    const float4 e = row[i];
-                    const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
-                    S1 = __builtin_fmaf(e.y, y, S1);
-                    SB = __builtin_fmaf(e.z, y, SB);
+                for (int i = 0; i < ilw; i += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 e = row[i + u];
+                        const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
+                        S1 = __builtin_fmaf(e.y, y, S1);
+                        SB = __builtin_fmaf(e.z, y, SB);
+                    }
                 }
                 {
                     const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(cl, ss, 1.0f));
@@ -286,7 +306,8 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 extern "C" size_t rtmi_f32fast_lds_bytes(int nlayers)
 {
     const size_t W = (size_t)nlayers + 1;
-    size_t b = W * W * sizeof(float4) + 2 * W * sizeof(float4) + W * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
+    const size_t WS = (W + 3) & ~(size_t)3;
+    size_t b = W * WS * sizeof(float4) + 2 * W * sizeof(float4) + W * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
     b += (size_t)4 * F32F_TILE * sizeof(float);                 // sz, sR, tout, pout
     b += ((W + 3) & ~(size_t)3) * sizeof(uint32_t);             // hist
     b += (size_t)F32F_TILE * sizeof(uint32_t);                  // sidx
