@@ -576,14 +576,14 @@ def main():
         # the roof that actually binds: the fp64 vector ALU.  One wave-instruction occupies a SIMD for 4 cycles
         # (v_rsq/v_rcp_f64: 16), i.e. 16 lanes per clock and SIMD = FP64_VALU_PEAK_TFLOPS / 2 lane-instructions per
         # second over the chip.  Executed instructions come from the same PMC passes (SQ_INSTS_VALU); the useful part
-        # is the layer terms the kernel still has to evaluate: 27.6 per travel time on this workload (23.5 in the solve
-        # loop, counted by the instrumented kernel, profiles/r02i/phase_clocks.txt, + the first evaluation of the 93 %
+        # is the layer terms the kernel still has to evaluate: 23.2 per travel time on this workload (19.1 in the solve
+        # loop, counted by the instrumented kernel, profiles/r03d/phase_clocks.txt, + the first evaluation of the 93 %
         # of sources below the top layer) x 35 instructions each.  (The reference's own arithmetic makes 41.7 per
-        # travel time: a third of them are proven unnecessary)
+        # travel time: nearly half of them are proven unnecessary)
         peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
         res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
-                            "useful_term_instr_per_travel_time": 27.6 * 35,
-                            "useful_frac_of_peak": 27.6 * 35 * value / peak_lane_instr,
+                            "useful_term_instr_per_travel_time": 23.2 * 35,
+                            "useful_frac_of_peak": 23.2 * 35 * value / peak_lane_instr,
                             "note": "fp64 VALU issue is the binding roof (DESIGN.md section 4.2)"}
         mc = measured_counters()
         if mc is not None and mc[1] and n == 1_000_000 and kern_ms:
