@@ -1301,6 +1301,15 @@ __device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<
     const T q = solver_quotient(f, fp, st != ST_DONE);  // deltax of solvebst (:384) and of solve (:294)
     const bool neg = f < T(0.0);
     const bool small = fabs(f) < T(0.1);     // abs(fx) < tol (:287), abs(fmid) < tol (:394)
+    // The Newton update of solve (:298-304), once for both states that take one: a lane in ST_NEWTON has x == xe (both are
+    // set together, everywhere), and the trip in which solvebst leaves is solve's first trip at xmid = xe (below).
+    T xnew = s.xe - q;                       // x = x - deltax (:298)
+    // ... and the trip after it is not made when it would only confirm convergence at xnew (newton_lands_converged)
+    bool lands = false;
+    if (use_pred)
+        lands = !small && newton_lands_converged(t, s, s.xe, f, q, xnew);
+    if (xnew > s.vmi)
+        xnew = s.clampv;                     // (:299-304)
     if (st == ST_BIS) {
         const T xb1 = neg ? s.xe : s.xb;     // `if (fmid < 0) x = xmid` (:371-373)
         const T check_x = xb1 - q;           // (:386)
@@ -1314,13 +1323,7 @@ __device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<
         // operands.  Its first iteration is therefore taken here (as lane_advance_init does for solve(p0)): one
         // evaluation less for nearly every bisection source.
         const bool fuse = done && (neg || (!zero && jump));
-        T xnew = s.xe - q;                   // x = x - deltax (:298)
-        // ... and solve's SECOND trip is not made when it would only confirm convergence (newton_lands_converged)
-        bool pred = false;
-        if (use_pred)
-            pred = fuse && !small && newton_lands_converged(t, s, s.xe, f, q, xnew);
-        if (xnew > s.vmi)
-            xnew = s.clampv;                 // (:299-304)
+        const bool pred = fuse && lands;
         const bool f_conv = (fuse && small) || pred, f_go = fuse && !small;
         s.xb = xb2;
         s.dx = done ? s.dx : dxh;
@@ -1330,14 +1333,8 @@ __device__ __forceinline__ void lane_advance_solve(const LayerTable<T> &t, Lane<
         s.conv = f_conv ? true : s.conv;     // (:288)
         s.st = f_conv ? ST_DONE : (done ? ST_NEWTON : ST_BIS);
     } else if (st == ST_NEWTON) {
-        T xnew = s.x - q;                    // x = x - deltax (:298)
         const bool last = (s.k == 15);
-        // the next trip would only confirm convergence at xnew (newton_lands_converged): the source is finished now
-        bool pred = false;
-        if (use_pred)
-            pred = !small && !last && newton_lands_converged(t, s, s.x, f, q, xnew);
-        if (xnew > s.vmi)
-            xnew = s.clampv;                 // (:299-304)
+        const bool pred = lands && !last;    // (the 15th trip is followed by the inverted test, not by a trip of the loop)
         s.conv = (small || pred) ? true : s.conv;  // (:288)
         s.x = small ? s.x : xnew;
         s.xe = small ? s.xe : xnew;

@@ -922,7 +922,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             if (was_busy && s.st == ST_DONE) {
                 rp[slot] = s.x;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // p before the flag the time pass polls
-                rk[slot] |= s.conv ? (RTMI_RK_DONE | RTMI_RK_CONV) : RTMI_RK_DONE;
+                atomicOr(&rk[slot], s.conv ? (RTMI_RK_DONE | RTMI_RK_CONV) : RTMI_RK_DONE);  // one ds_or, no round trip
             }
         }
         // Rounds with express waves go on WITHOUT a barrier: the local waves, which leave the solve loop while the
