@@ -32,6 +32,10 @@ enum : int {
 #ifndef RTMI_PREDICT
 #define RTMI_PREDICT 1  // 0: every evaluation of solve() is made (A/B builds; see newton_lands_converged)
 #endif
+// Launches with row tables (every model <= RTMI_ROWS_MAX_NL interfaces) lay the table out for RTMI_ROWS_MAX_NL interfaces
+// whatever the model has: the arrays then sit at COMPILE-TIME offsets from the table's base, i.e. in the immediate offsets of
+// the LDS instructions instead of a dozen scalar registers that the solve loop has not got (it spills them).
+#define RTMI_TABLE_STRIDE_OF(nlayers, rows) ((rows) ? RTMI_ROWS_MAX_NL + 2 : (nlayers) + 2)
 #define RTMI_TABLE_STRIDE(nlayers) ((nlayers) + 2)
 // Models of up to RTMI_ROWS_MAX_NL interfaces also get the pair table once per stack height ("rows", see LayerTable);
 // `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
@@ -41,8 +45,8 @@ enum : int {
 // `skiptab` (like `rows`) is decided per LAUNCH from its largest model, so that the size is monotone in nlayers
 #define RTMI_TABLE_NARRAYS(skiptab) (RTMI_TABLE_ARRAYS + ((skiptab) ? 3 : 0))
 #define RTMI_TABLE_ELEMS(nlayers, rows, skiptab) \
-    (((size_t)RTMI_TABLE_NARRAYS(skiptab) * RTMI_TABLE_STRIDE(nlayers) + 1) / 2 * 2 + \
-     ((rows) ? (size_t)2 * ((nlayers) + 1) * ((nlayers) + 1) : 0))
+    (((size_t)RTMI_TABLE_NARRAYS(skiptab) * RTMI_TABLE_STRIDE_OF(nlayers, rows) + 1) / 2 * 2 + \
+     ((rows) ? (size_t)2 * (RTMI_ROWS_MAX_NL + 1) * (RTMI_ROWS_MAX_NL + 1) : 0))
 template <typename T>
 struct alignas(2 * sizeof(T)) LayerPair {
     T hv, vv;
@@ -76,10 +80,14 @@ struct LayerTable {
     T *HC;    // } partial layer hl * SC[il] (0 if it is the fastest), the fastest layers HC[il] * x / sqrt(1 - x^2 vmax^2)
 };
 
-template <typename T>
+template <bool ROWS = false, typename T>
 __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool rows, bool skiptab)
 {
-    const int n1 = RTMI_TABLE_STRIDE(nlayers);
+    const int n1 = ROWS ? RTMI_ROWS_MAX_NL + 2 : RTMI_TABLE_STRIDE(nlayers);  // ROWS: a constant (see RTMI_TABLE_STRIDE_OF)
+    if (ROWS) {
+        skiptab = true;  // RTMI_ROWS_MAX_NL <= RTMI_SKIP_MAX_NL: the launcher sets both (a constant for the offsets below)
+        rows = true;
+    }
     LayerTable<T> t;
     t.HW = reinterpret_cast<LayerPair<T> *>(lds);
     t.nul = nlayers + 1;
@@ -101,7 +109,7 @@ __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool r
     t.SC = skiptab ? lds + 17 * n1 : nullptr;
     t.HC = skiptab ? lds + 18 * n1 : nullptr;
     t.HWR = rows ? reinterpret_cast<LayerPair<T> *>(lds + ((size_t)RTMI_TABLE_NARRAYS(skiptab) * n1 + 1) / 2 * 2) : nullptr;
-    t.row_len = nlayers + 1;
+    t.row_len = ROWS ? RTMI_ROWS_MAX_NL + 1 : nlayers + 1;
     return t;
 }
 

@@ -284,24 +284,21 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
 #pragma unroll
     for (int j = 0; j < PF; ++j)
         zw[j] = depth_of(0, wib + j * nwib);
-    const LayerTable<T> t = carve_table(lds, a.nlayers, ROWS, a.skiptab != 0);
+    const LayerTable<T> t = carve_table<ROWS>(lds, a.nlayers, ROWS, a.skiptab != 0);
     // DET: the records' slots decide the order of the floating-point residual sum (the batch API's logL), so the sort must
     // be the same on every run: ranks by ballots.  Every other form of the kernel (travel times only; the sampler's
     // order-independent sums) is indifferent to WHICH slot of its bin a record gets: ranks by one LDS atomic per lane.
     constexpr bool DET = WANT_SS && !INC;
     T ss = T(0.0);  // this thread's sum of squared residuals (fused logL)
 
-    T *rR = reinterpret_cast<T *>(reinterpret_cast<char *>(lds) +
-                                  (RTMI_TABLE_ELEMS(a.nlayers, ROWS, a.skiptab) * sizeof(T) + 15) / 16 * 16);  // offset }
-    T *rz = rR + slots;                                  // depth             } sorted by descending layer
-    T *rp = rz + slots;                                  // p0, later p_final }
-    uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
-    uint32_t *tnl = rk + slots;                               // nl per local index (between the sort passes)
-    uint32_t *hist = tnl + slots;                             // [16 waves][64 bins] counts, then first slots
+    // LDS behind the table: first everything of FIXED size (bin counters, queue words, the hand-over ring) -- with row tables
+    // the table's size is a constant, so these sit at compile-time offsets and cost the solve loop no scalar registers -- then
+    // the per-record arrays, whose positions depend on `slots`.
+    char *fx = reinterpret_cast<char *>(lds) + (RTMI_TABLE_ELEMS(a.nlayers, ROWS, a.skiptab) * sizeof(T) + 15) / 16 * 16;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(fx);        // [16 waves][64 bins] counts, then first slots
     uint32_t *qctl = hist + 16 * 64;                          // [0] queue head, [1] records sorted, [2] long, [3] short
-    uint16_t *order = reinterpret_cast<uint16_t *>(qctl + 4); // solve order: slots of the long class, then the short
     // hand-over pool of the drain (see "wave retirement" below): RTMI_POOL suspended lane states
-    T *pl_xe = reinterpret_cast<T *>(reinterpret_cast<char *>(order) + (((size_t)slots * sizeof(uint16_t) + 7) / 8) * 8);
+    T *pl_xe = reinterpret_cast<T *>(qctl + 4);
     T *pl_x = pl_xe + RTMI_POOL;
     T *pl_xb = pl_x + RTMI_POOL;
     T *pl_dx = pl_xb + RTMI_POOL;
@@ -311,6 +308,15 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     typedef __attribute__((address_space(3))) int lds_int;
     volatile lds_int *pl_ready = (volatile lds_int *)(pl_state + RTMI_POOL);
     volatile lds_int *pl_ctl = pl_ready + RTMI_POOL;            // [0] tail (reserved), [1] head (claimed), [2] local waves still solving
+    // (pl_ctl[4 .. 4 + 9]: cls_base, below.)  The record arrays follow the 16 control words; every size above is a multiple
+    // of 16 bytes, so they are 16-byte aligned.  [Derived from the GENERIC pointer pl_state: an address_space(3) pointer
+    // turned into an integer is a bare LDS offset, not an address.]
+    T *rR = reinterpret_cast<T *>(pl_state + 2 * RTMI_POOL + 16);  // offset }
+    T *rz = rR + slots;                                  // depth             } sorted by descending layer
+    T *rp = rz + slots;                                  // p0, later p_final }
+    uint32_t *rk = reinterpret_cast<uint32_t *>(rp + slots);  // loc | nl << 13 | conv << 31
+    uint32_t *tnl = rk + slots;                               // nl per local index (between the sort passes)
+    uint16_t *order = reinterpret_cast<uint16_t *>(tnl + slots); // solve order: slots of the long class, then the short
     // exact solve order: per 64-slot chunk, counts and first order[] positions of the two classes
     uint32_t *cls_base = reinterpret_cast<uint32_t *>(pl_state + 2 * RTMI_POOL + 4);  // [9] first order[] position of a class
     // per 64-slot chunk, counts and first positions of the four classes as 16-bit fields of a 64-bit word; they
