@@ -11,7 +11,7 @@ cd $R
 echo "== bench (C2 headline, with drop-in block and CPU baseline)"; python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
 echo "== bench c4"; python bench.py --workload c4 --steps 20 > $O/bench_c4.json 2> $O/bench_c4.err
 echo "== bench pt"; python bench.py --workload pt --steps 300 --warmup 30 > $O/bench_pt.json 2> $O/bench_pt.err; tail -c 300 $O/bench_pt.json
-echo "== bench pt at config 4's per-GPU share"; python bench.py --workload pt --nsrc 100000 --kmax 30 --steps 60 --warmup 20 > $O/bench_pt_config4_share.json 2> $O/bench_pt_c4.err
+echo "== bench pt at config 4's per-GPU share (warm-up past the engine trial, which opens once the sweeps have kmax node slots)"; python bench.py --workload pt --nsrc 100000 --kmax 30 --steps 60 --warmup 50 > $O/bench_pt_config4_share.json 2> $O/bench_pt_c4.err
 echo "== bench c5 (fp32 fast) + the three single-GPU paths at config 5's shape"; python bench.py --workload c5 > $O/bench_c5.json 2> $O/bench_c5.err
 python profiles/f32fast_bench.py > $O/f32fast_bench.txt 2>&1; python profiles/f32fast_bench.py 10000000 > $O/f32fast_bench_1e7.txt 2>&1
 echo "== 2 ranks on this one GPU, gloo (self-launched by bench.py --gpus 2)"

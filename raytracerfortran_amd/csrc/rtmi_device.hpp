@@ -32,10 +32,16 @@ enum : int {
 #ifndef RTMI_PREDICT
 #define RTMI_PREDICT 1  // 0: every evaluation of solve() is made (A/B builds; see newton_lands_converged)
 #endif
-// Launches with row tables (every model <= RTMI_ROWS_MAX_NL interfaces) lay the table out for RTMI_ROWS_MAX_NL interfaces
-// whatever the model has: the arrays then sit at COMPILE-TIME offsets from the table's base, i.e. in the immediate offsets of
-// the LDS instructions instead of a dozen scalar registers that the solve loop has not got (it spills them).
-#define RTMI_TABLE_STRIDE_OF(nlayers, rows) ((rows) ? RTMI_ROWS_MAX_NL + 2 : (nlayers) + 2)
+// Table forms of the fused kernel (a template parameter, chosen per launch from its largest model):
+//   0  stride nlayers + 2, decided at run time                                   (any model)
+//   1  row tables (below) and a CONSTANT stride for RTMI_ROWS_MAX_NL interfaces   (every model <= 20 interfaces)
+//   2  a CONSTANT stride for RTMI_FIXED_MAX_NL interfaces, no row tables          (every model <= 32: the sampler's k <= 30)
+// With a constant stride the arrays sit at COMPILE-TIME offsets from the table's base -- in the immediate offsets of the
+// LDS instructions instead of a dozen scalar registers that the solve loop has not got (it spills them) -- and so does
+// everything of fixed size that is laid out behind the table.
+#define RTMI_FIXED_MAX_NL 32
+#define RTMI_TABLE_FORM(max_nlayers) ((max_nlayers) <= RTMI_ROWS_MAX_NL ? 1 : ((max_nlayers) <= RTMI_FIXED_MAX_NL ? 2 : 0))
+#define RTMI_TABLE_STRIDE_OF(nlayers, tf) ((tf) == 1 ? RTMI_ROWS_MAX_NL + 2 : ((tf) == 2 ? RTMI_FIXED_MAX_NL + 2 : (nlayers) + 2))
 #define RTMI_TABLE_STRIDE(nlayers) ((nlayers) + 2)
 // Models of up to RTMI_ROWS_MAX_NL interfaces also get the pair table once per stack height ("rows", see LayerTable);
 // `rows` is decided per launch (from the largest model of the launch), so that the size is monotone in nlayers.
@@ -44,9 +50,9 @@ enum : int {
 #define RTMI_SKIP_MAX_NL 64   // deeper models: no skipping of provably idle bisection trips (the bound's table is O(nlayers^2))
 // `skiptab` (like `rows`) is decided per LAUNCH from its largest model, so that the size is monotone in nlayers
 #define RTMI_TABLE_NARRAYS(skiptab) (RTMI_TABLE_ARRAYS + ((skiptab) ? 3 : 0))
-#define RTMI_TABLE_ELEMS(nlayers, rows, skiptab) \
-    (((size_t)RTMI_TABLE_NARRAYS(skiptab) * RTMI_TABLE_STRIDE_OF(nlayers, rows) + 1) / 2 * 2 + \
-     ((rows) ? (size_t)2 * (RTMI_ROWS_MAX_NL + 1) * (RTMI_ROWS_MAX_NL + 1) : 0))
+#define RTMI_TABLE_ELEMS(nlayers, tf, skiptab) \
+    (((size_t)RTMI_TABLE_NARRAYS(skiptab) * RTMI_TABLE_STRIDE_OF(nlayers, (int)(tf)) + 1) / 2 * 2 + \
+     ((int)(tf) == 1 ? (size_t)2 * (RTMI_ROWS_MAX_NL + 1) * (RTMI_ROWS_MAX_NL + 1) : 0))
 template <typename T>
 struct alignas(2 * sizeof(T)) LayerPair {
     T hv, vv;
@@ -80,13 +86,14 @@ struct LayerTable {
     T *HC;    // } partial layer hl * SC[il] (0 if it is the fastest), the fastest layers HC[il] * x / sqrt(1 - x^2 vmax^2)
 };
 
-template <bool ROWS = false, typename T>
+template <int TF = 0, typename T>
 __device__ __forceinline__ LayerTable<T> carve_table(T *lds, int nlayers, bool rows, bool skiptab)
 {
-    const int n1 = ROWS ? RTMI_ROWS_MAX_NL + 2 : RTMI_TABLE_STRIDE(nlayers);  // ROWS: a constant (see RTMI_TABLE_STRIDE_OF)
-    if (ROWS) {
-        skiptab = true;  // RTMI_ROWS_MAX_NL <= RTMI_SKIP_MAX_NL: the launcher sets both (a constant for the offsets below)
-        rows = true;
+    constexpr bool ROWS = TF == 1;
+    const int n1 = RTMI_TABLE_STRIDE_OF(nlayers, TF);  // forms 1 and 2: a constant
+    if (TF != 0) {
+        skiptab = true;  // RTMI_FIXED_MAX_NL <= RTMI_SKIP_MAX_NL: the launcher sets both (a constant for the offsets below)
+        rows = ROWS;
     }
     LayerTable<T> t;
     t.HW = reinterpret_cast<LayerPair<T> *>(lds);

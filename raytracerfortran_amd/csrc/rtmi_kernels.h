@@ -66,7 +66,7 @@ struct FusedArgsT {
     int refill_min;              // idle lanes that trigger a refill of the wave (1..64)
     int slots;                   // records a workgroup holds in LDS per round (multiple of 64)
     int tail_group;              // end-game: wave group g stops refilling below g * tail_group queued records (0 = off)
-    int rows;                    // set by the launcher: layer tables with one row per stack height (small models)
+    int rows;                    // set by the launcher: table form (rtmi_device.hpp): 0, 1 = row tables + constant stride, 2 = constant stride
     int skiptab;                 // set by the launcher: the layer tables carry the bound of bisection_skip (<= 64 interfaces)
     int promote_age;             // local waves hand a source to the express waves after this many trips (0 = off)
     int retire_max;              // drain: waves 4.. hand over their last <= retire_max live lanes and leave (0 = off)

@@ -228,9 +228,11 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // template parameter so that each instantiation holds one form of the evaluation loop only (code size).
 // The body is a device function of (model m, workgroup row bx of gx rows): the kernel below calls it with the launch's
 // grid indices, the persistent sweep kernel of the tempering sampler (pt_sweep_kernel) once per proposal slot.
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, bool ROWS, bool INCR = false>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, int TF, bool INCR = false>
 __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const int bx, const int gx, T *lds)
 {
+    // (`a` by value; by const reference -- fields re-read from the argument block where they are used -- was measured: C2 +2 %)
+    constexpr bool ROWS = TF == 1;  // table form (rtmi_device.hpp): 1 = row tables, 1 and 2 = constant table stride
     // INC: the sampler's form of the likelihood -- squared residuals are accumulated EXACTLY (Acc192, rtmi_device.hpp), so
     // the sum does not depend on who adds what in which order, and (with a.d_inc) unaffected sources come from the cache
     constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
@@ -284,7 +286,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
 #pragma unroll
     for (int j = 0; j < PF; ++j)
         zw[j] = depth_of(0, wib + j * nwib);
-    const LayerTable<T> t = carve_table<ROWS>(lds, a.nlayers, ROWS, a.skiptab != 0);
+    const LayerTable<T> t = carve_table<TF>(lds, a.nlayers, ROWS, a.skiptab != 0);
     // DET: the records' slots decide the order of the floating-point residual sum (the batch API's logL), so the sort must
     // be the same on every run: ranks by ballots.  Every other form of the kernel (travel times only; the sampler's
     // order-independent sums) is indifferent to WHICH slot of its bin a record gets: ranks by one LDS atomic per lane.
@@ -294,7 +296,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // LDS behind the table: first everything of FIXED size (bin counters, queue words, the hand-over ring) -- with row tables
     // the table's size is a constant, so these sit at compile-time offsets and cost the solve loop no scalar registers -- then
     // the per-record arrays, whose positions depend on `slots`.
-    char *fx = reinterpret_cast<char *>(lds) + (RTMI_TABLE_ELEMS(a.nlayers, ROWS, a.skiptab) * sizeof(T) + 15) / 16 * 16;
+    char *fx = reinterpret_cast<char *>(lds) + (RTMI_TABLE_ELEMS(a.nlayers, TF, TF != 0 ? 1 : a.skiptab) * sizeof(T) + 15) / 16 * 16;
     uint32_t *hist = reinterpret_cast<uint32_t *>(fx);        // [16 waves][64 bins] counts, then first slots
     uint32_t *qctl = hist + 16 * 64;                          // [0] queue head, [1] records sorted, [2] long, [3] short
     // hand-over pool of the drain (see "wave retirement" below): RTMI_POOL suspended lane states
@@ -1085,11 +1087,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     }
 }
 
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, bool ROWS = false, bool INCR = false>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG = false, int TF = 0, bool INCR = false>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // storage for either element type
-    fused_body<T, WANT_P, WANT_T, WANT_SS, DIAG, ROWS, INCR>(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x,
+    fused_body<T, WANT_P, WANT_T, WANT_SS, DIAG, TF, INCR>(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x,
                                                              reinterpret_cast<T *>(lds_raw));
 }
 
@@ -1153,7 +1155,7 @@ __device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chai
     }
 }
 
-template <bool ROWS, bool INCR>
+template <int TF, bool INCR>
 __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, PtSweepArgs w)
 {
     using namespace rtmi_pt_dev;
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArg
             const int kc = __builtin_amdgcn_readfirstlane(dp->k[chain]);
             S_c = 2 * kc < S_c ? 2 * kc : S_c;
         }
-        fused_body<double, false, false, true, false, ROWS, INCR>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
+        fused_body<double, false, false, true, false, TF, INCR>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
         __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
         if (threadIdx.x == 0) {
             __threadfence();
@@ -1441,7 +1443,7 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
     const int64_t chunks_per_block = (nchunks + nblocks - 1) / nblocks;
     if (waves > chunks_per_block)
         waves = (int)chunks_per_block;  // small inputs: no idle waves
-    const size_t table = (RTMI_TABLE_ELEMS(max_nlayers, max_nlayers <= RTMI_ROWS_MAX_NL, max_nlayers <= RTMI_SKIP_MAX_NL) * elem_bytes + 15) / 16 * 16;
+    const size_t table = (RTMI_TABLE_ELEMS(max_nlayers, RTMI_TABLE_FORM(max_nlayers), max_nlayers <= RTMI_SKIP_MAX_NL) * elem_bytes + 15) / 16 * 16;
     const size_t fixed = table + (16 * 64 + 4) * sizeof(uint32_t) + 16 +
                          (size_t)RTMI_POOL * (4 * elem_bytes + 3 * sizeof(int)) + 4 * sizeof(int) +
                          (128 + 128) * sizeof(uint32_t);
@@ -1461,11 +1463,14 @@ extern "C" int rtmi_fused_geometry(int64_t nsrc, int max_nlayers, int nmodels, i
 template <typename T, bool P, bool WT, bool S, bool DIAG = false>
 static hipError_t set_fused_lds_limit()
 {
-    // dynamic LDS above 64 KiB needs the opt-in (both forms of the layer table)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, false>),
+    // dynamic LDS above 64 KiB needs the opt-in (the three forms of the layer table)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, P, WT, S, DIAG, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
@@ -1489,10 +1494,13 @@ static hipError_t prepare_fused_t()
     if (e == hipSuccess)
         e = set_fused_lds_limit<T, false, false, true>();
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, false, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, 0, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, true, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, 1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi::fused_kernel<T, false, false, true, false, 2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         attr_set = true;
@@ -1521,8 +1529,8 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     }
     FusedArgsT<T> a = args;
     a.max_nlayers = max_nlayers;  // what the LDS table is sized for: the kernel checks d_nlayers[m] against it
-    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;
-    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;  // launch-wide: the layer tables carry one row per stack height
+    a.rows = RTMI_TABLE_FORM(max_nlayers);                // table form (rtmi_device.hpp): 1 = row tables, 1 / 2 = constant stride
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;  // launch-wide
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
@@ -1538,19 +1546,23 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     const bool want_ss = a.d_obs != nullptr;
 #define RTMI_LAUNCH_FUSED(P, WT, S, DG)                                                                          \
     do {                                                                                                        \
-        if (a.rows)                                                                                             \
-            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, true>), grid, block, lds_bytes, stream, a);       \
+        if (a.rows == 1)                                                                                        \
+            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, 1>), grid, block, lds_bytes, stream, a);          \
+        else if (a.rows == 2)                                                                                   \
+            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, 2>), grid, block, lds_bytes, stream, a);          \
         else                                                                                                    \
-            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, false>), grid, block, lds_bytes, stream, a);      \
+            hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, 0>), grid, block, lds_bytes, stream, a);          \
     } while (0)
     if (want_ss && want_t)
         RTMI_LAUNCH_FUSED(false, true, true, false);
     else if (want_ss && a.d_partial_x && std::is_same<T, double>::value) {
         // the tempering sampler's form of the likelihood (exact sums, optionally incremental: PtInc): its own instantiation
-        if (a.rows)
-            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, true, true>), grid, block, lds_bytes, stream, a);
+        if (a.rows == 1)
+            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, 1, true>), grid, block, lds_bytes, stream, a);
+        else if (a.rows == 2)
+            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, 2, true>), grid, block, lds_bytes, stream, a);
         else
-            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, false, true>), grid, block, lds_bytes, stream, a);
+            hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, 0, true>), grid, block, lds_bytes, stream, a);
     } else if (want_ss)
         RTMI_LAUNCH_FUSED(false, false, true, false);
     else if (want_p)
@@ -1586,7 +1598,7 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     const PtDev *dp = static_cast<const PtDev *>(ptdev);  // a DEVICE copy of the handle's view
     PtSweepArgs ws = *w;
     a.max_nlayers = max_nlayers;
-    a.rows = max_nlayers <= RTMI_ROWS_MAX_NL ? 1 : 0;
+    a.rows = RTMI_TABLE_FORM(max_nlayers);
     a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
@@ -1603,10 +1615,14 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     }
     // (a chain's share of the sources may take several rounds of its workgroups' LDS: fused_body loops over them)
     ws.xcd_map = (nchains % 8 == 0) ? 1 : 0;  // measured: 1.18 ms per sweep against 1.21 with a chain spread over the XCDs
-    const void *fn = a.d_partial_x ? (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, true>)
-                                       : reinterpret_cast<const void *>(&pt_sweep_kernel<false, true>))
-                             : (a.rows ? reinterpret_cast<const void *>(&pt_sweep_kernel<true, false>)
-                                       : reinterpret_cast<const void *>(&pt_sweep_kernel<false, false>));
+    // table form 2 (constant stride without row tables, models of 21 ... 32 interfaces) pays in the likelihood kernel
+    // (config 4's batch -2.8 %) but not with the body inlined into this kernel's slot loop (+2.7 %, measured): form 0 here
+    // (the LDS the geometry reserved for the larger table is simply not all used)
+    if (a.rows == 2)
+        a.rows = 0;
+    const void *fns[2][2] = {{reinterpret_cast<const void *>(&pt_sweep_kernel<0, false>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, false>)},
+                             {reinterpret_cast<const void *>(&pt_sweep_kernel<0, true>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, true>)}};
+    const void *fn = fns[a.d_partial_x ? 1 : 0][a.rows];
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
         return e;
