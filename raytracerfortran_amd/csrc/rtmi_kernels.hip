@@ -208,6 +208,9 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
     return nl_max <= 63 ? nl : (int)(((long long)nl * 63) / nl_max);
 }
 
+#ifndef RTMI_PRED_MIN_PER_LANE
+#define RTMI_PRED_MIN_PER_LANE 2  // records per lane from which a round consults newton_lands_converged (lane_advance_solve)
+#endif
 #ifndef RTMI_PREFETCH
 #define RTMI_PREFETCH 4      // chunks of source data a wave keeps in flight in the load / sort passes
 #endif
@@ -679,7 +682,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         // hand-overs pay once a round holds at least a record per lane (drain) or two (promotion); below that
         // every wave is in its end-game from the start
         const int promote_age = n_todo >= 2 * (int)blockDim.x ? a.promote_age : 0;
-        const bool use_pred = n_todo >= 2 * (int)blockDim.x && model_terms_nonneg(t);  // see lane_advance_solve
+        const bool use_pred = n_todo >= RTMI_PRED_MIN_PER_LANE * (int)blockDim.x && model_terms_nonneg(t);  // see lane_advance_solve
         const bool split = nwib > 4 && n_todo >= (int)blockDim.x && (a.retire_max > 0 || promote_age > 0);
         const bool local = split && wib >= 4;
         const bool express = split && wib < 4;
