@@ -9,4 +9,4 @@ from . import raymod  # noqa: F401
 from .raymod import (RtmiError, TraceRays, dff, dff7, dofullforwardproblem, init, load_library, loglhood_batch, set_option, set_sources,  # noqa: F401
                      trace_batch_device, trace_device, write_rays_dat)
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
