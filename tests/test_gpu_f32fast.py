@@ -14,38 +14,7 @@ import pytest
 from oracle import oracle as O
 
 
-def converged_times(v, d, off, dep):
-    """t(p*) with f(p*) = 0 to double-precision roundoff: monotone Newton in s = tan(theta) of the stack's fastest layer
-    (X(s) = s sum H r / sqrt(1 + c s^2) is concave increasing), sources grouped by layer.  Returns (t, p)."""
-    v, d, R, z = (np.asarray(a, np.float64) for a in (v, d, off, dep))
-    NL, n = d.size, R.size
-    cnt = np.searchsorted(d, z, side="right")
-    il = cnt.copy()
-    il[(cnt == NL) & (z == d[-1])] = NL - 1          # whichLayer's special case (:22-30)
-    t, p = np.empty(n), np.full(n, np.nan)
-    for L in range(NL + 1):
-        m = il == L
-        if not m.any():
-            continue
-        Rm, zm = R[m], z[m]
-        if L == 0:
-            t[m] = np.sqrt(zm * zm + Rm * Rm) / v[0]
-            continue
-        V = v[:L + 1]
-        vmax = V.max()
-        H = np.concatenate([[d[0]], np.diff(d[:L])])
-        c = (vmax - V) * (vmax + V) / (vmax * vmax)
-        hl = zm - d[L - 1]
-        A = np.concatenate([np.broadcast_to(H * V[:L] / vmax, (m.sum(), L)), (hl * V[L] / vmax)[:, None]], 1)
-        B = np.concatenate([np.broadcast_to(H / V[:L], (m.sum(), L)), (hl / V[L])[:, None]], 1)
-        s = Rm / A.sum(1)
-        for _ in range(60):
-            y = 1.0 / np.sqrt(1.0 + c[None, :] * (s * s)[:, None])
-            s = s + (Rm - s * (A * y).sum(1)) / (A * y ** 3).sum(1)
-        y = 1.0 / np.sqrt(1.0 + c[None, :] * (s * s)[:, None])
-        t[m] = np.sqrt(1.0 + s * s) * (B * y).sum(1)
-        p[m] = s / np.sqrt(1.0 + s * s) / vmax
-    return t, p
+from f32fast_ref import converged_times  # noqa: E402  (the converged double-precision solution of the reference's equations)
 
 
 def c5_model(nl=20, seed=2025):
