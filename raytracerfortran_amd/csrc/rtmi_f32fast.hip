@@ -48,7 +48,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     float4 *diag2 = diag + W;                                    // [W] {sum of H r over the stack's fastest full layers, sum of H r / sqrt(c)
                                                                  //      over its slower ones, 1 / sqrt(c_l) (0 if the own layer is a fastest one), 0}
     float *vmi = reinterpret_cast<float *>(diag2 + W);           // [W] 1 / vmax of the stack
-    float *D = vmi + W;                                          // [NL] interface depths
+    float *D = vmi + ((W + 3) & ~3);                             // [NL] interface depths (every array below starts 16-byte aligned)
     float *sz = D + ((NL + 3) & ~3);                             // [TILE] depth, sorted by layer
     float *sR = sz + F32F_TILE;                                  // [TILE] offset
     float *tout = sR + F32F_TILE;                                // [TILE] results in input order
@@ -326,7 +326,7 @@ extern "C" size_t rtmi_f32fast_lds_bytes(int nlayers)
 {
     const size_t W = (size_t)nlayers + 1;
     const size_t WS = (W + 3) & ~(size_t)3;
-    size_t b = W * WS * sizeof(float4) + 2 * W * sizeof(float4) + W * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
+    size_t b = W * WS * sizeof(float4) + 2 * W * sizeof(float4) + ((W + 3) & ~(size_t)3) * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
     b += (size_t)4 * F32F_TILE * sizeof(float);                 // sz, sR, tout, pout
     b += ((W + 3) & ~(size_t)3) * sizeof(uint32_t);             // hist
     b += (size_t)F32F_TILE * sizeof(uint32_t);                  // sidx
