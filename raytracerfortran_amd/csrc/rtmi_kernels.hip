@@ -231,7 +231,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 // template parameter so that each instantiation holds one form of the evaluation loop only (code size).
 // The body is a device function of (model m, workgroup row bx of gx rows): the kernel below calls it with the launch's
 // grid indices, the persistent sweep kernel of the tempering sampler (pt_sweep_kernel) once per proposal slot.
-template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, int TF, bool INCR = false>
+template <typename T, bool WANT_P, bool WANT_T, bool WANT_SS, bool DIAG, int TF, bool INCR = false, bool SWEEP = false>
 __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const int bx, const int gx, T *lds)
 {
     // (`a` by value; by const reference -- fields re-read from the argument block where they are used -- was measured: C2 +2 %)
@@ -299,7 +299,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // LDS behind the table: first everything of FIXED size (bin counters, queue words, the hand-over ring) -- with row tables
     // the table's size is a constant, so these sit at compile-time offsets and cost the solve loop no scalar registers -- then
     // the per-record arrays, whose positions depend on `slots`.
-    char *fx = reinterpret_cast<char *>(lds) + (RTMI_TABLE_ELEMS(a.nlayers, TF, TF != 0 ? 1 : a.skiptab) * sizeof(T) + 15) / 16 * 16;
+    // (SWEEP: inlined into the slot loop of the persistent sweep kernel, whose register allocation is at the edge, the fully
+    // constant form of this offset -- skiptab is 1 whenever TF != 0 -- makes the compiler spill FOUR times as many values to
+    // scratch, all over the solve loop: sweep 0.92 -> 1.01 ms, bisected in profiles/r03g/pt_bisect.txt.  There the launch's
+    // value is read instead; everywhere else the constant is the better form.)
+    char *fx = reinterpret_cast<char *>(lds) + (RTMI_TABLE_ELEMS(a.nlayers, TF, (TF != 0 && !SWEEP) ? 1 : a.skiptab) * sizeof(T) + 15) / 16 * 16;
     uint32_t *hist = reinterpret_cast<uint32_t *>(fx);        // [16 waves][64 bins] counts, then first slots
     uint32_t *qctl = hist + 16 * 64;                          // [0] queue head, [1] records sorted, [2] long, [3] short
     // hand-over pool of the drain (see "wave retirement" below): RTMI_POOL suspended lane states
@@ -1211,7 +1215,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_kernel(FusedArg
             const int kc = __builtin_amdgcn_readfirstlane(dp->k[chain]);
             S_c = 2 * kc < S_c ? 2 * kc : S_c;
         }
-        fused_body<double, false, false, true, false, TF, INCR>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
+        fused_body<double, false, false, true, false, TF, INCR, true>(a, chain, row, gx, reinterpret_cast<double *>(lds_raw));
         __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
         if (threadIdx.x == 0) {
             __threadfence();
