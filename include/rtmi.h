@@ -155,6 +155,17 @@ int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* = rtmi_pt_run(h, nsweeps, 0, NU
 int rtmi_pt_stats(const rtmi_pt *h, int64_t *out8);
 /* incremental likelihood: sources of proposals traced / taken from the residual cache so far */
 int rtmi_pt_likelihood_counts(const rtmi_pt *h, int64_t *traced, int64_t *cached);
+/* position of every chain's counter-based random stream (draws taken so far), ctr[nchains]: part of a chain's state --
+ * two runs whose chains AND stream positions agree have taken the same draws for the same decisions */
+int rtmi_pt_stream_positions(rtmi_pt *h, uint64_t *ctr);
+/* The speculative step (RTMI_PT_SPECULATE = model rows per chain, default 4; 0 = one proposal at a time): a perturbation
+ * is accepted about one time in five, and the chain's random stream is counter-based, so the proposals of the next slots
+ * ASSUMING REJECTION are known in advance; up to that many are evaluated side by side in one likelihood pass and decided in
+ * order with the draws the one-at-a-time sampler would take -- the first accepted one becomes the state, the ones behind
+ * it are discarded.  Chains, statistics and stream positions are bit-identical to RTMI_PT_SPECULATE=0 (the sums are exact).
+ * out4: rows per chain (1 = off), models evaluated and then discarded, engine in use (-1 undecided, 0 per-slot launches,
+ * 1 persistent launch), 1 if the handle's source set is kept sorted by depth. */
+int rtmi_pt_speculation(rtmi_pt *h, int64_t *out4);
 
 /*
  * Temperature ladder and exchange.  level[c] = temperature level of GLOBAL chain c (replicated on every rank),

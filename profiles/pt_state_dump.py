@@ -8,6 +8,10 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from raytracerfortran_amd import raymod
 raymod.LIB_PATH = os.path.abspath(sys.argv[1])
+import ctypes
+_probe = ctypes.CDLL(raymod.LIB_PATH)   # an older build may lack newer entry points: they are not what is being compared
+for _name in [n for n in raymod.SIGNATURES if not hasattr(_probe, n)]:
+    del raymod.SIGNATURES[_name]
 import raytracerfortran_amd as rt
 from raytracerfortran_amd import tempering as T
 rt.load_library(); rt.init(0)

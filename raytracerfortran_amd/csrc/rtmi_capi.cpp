@@ -186,8 +186,8 @@ int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus)
 int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
                  const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream,
-                 const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop, unsigned long long *d_inc_counts,
-                 unsigned long long *d_partial_x)
+                 const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts,
+                 unsigned long long *d_partial_x, int part_stride)
 {
     const Tuning tn = tuning_snapshot();
     int *d_status = nullptr;
@@ -216,10 +216,10 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
         fa.d_partial = d_partial;
         if (d_partial_x && d_obs && !d_timeP) {  // the sampler's form of the sums (exact), optionally incremental
             fa.d_partial_x = d_partial_x;
-            if (d_inc && d_r2cur && d_r2prop) {
+            fa.part_stride = part_stride;
+            if (d_inc && d_r2) {
                 fa.d_inc = d_inc;
-                fa.d_r2cur = d_r2cur;
-                fa.d_r2prop = d_r2prop;
+                fa.d_r2 = d_r2;
                 fa.d_inc_counts = d_inc_counts;
             }
         }
@@ -253,8 +253,8 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
 int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
-                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2cur, double *d_r2prop,
-                    unsigned long long *d_inc_counts, unsigned long long *d_partial_x)
+                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc, double *d_r2,
+                    unsigned long long *d_inc_counts, unsigned long long *d_partial_x, int part_stride)
 {
     const rtmi::PtSweepArgs *w = static_cast<const rtmi::PtSweepArgs *>(sweep_args);
     const Tuning tn = tuning_snapshot();
@@ -285,10 +285,10 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
     fa.d_obs = d_obs;
     fa.d_partial = d_partial;
     fa.d_partial_x = d_partial_x;
-    if (d_partial_x && d_inc && d_r2cur && d_r2prop) {
+    fa.part_stride = part_stride;
+    if (d_partial_x && d_inc && d_r2) {
         fa.d_inc = d_inc;
-        fa.d_r2cur = d_r2cur;
-        fa.d_r2prop = d_r2prop;
+        fa.d_r2 = d_r2;
         fa.d_inc_counts = d_inc_counts;
     }
     const hipError_t e = rtmi_launch_pt_sweep(&fa, ptdev, ptdev_bytes, w, nchains, max_nlayers, cus, tn.solve_waves, stream);

@@ -77,8 +77,8 @@ int num_cus_for_current_device();
 int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nmodels,
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                  double *d_timeP, const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out,
-                 hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2cur = nullptr, double *d_r2prop = nullptr,
-                 unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr);
+                 hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2 = nullptr,
+                 unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0);
 // whether launch_batch takes the fused kernel for this many sources (current knobs)
 bool batch_is_fused(int64_t nsrc);
 // workgroups per model (= partial sums per model) launch_batch will use for this shape
@@ -89,9 +89,8 @@ int batch_grid_x(int nmodels, int max_nlayers, int64_t nsrc, int cus);
 int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains,
                     int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
-                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2cur = nullptr,
-                    double *d_r2prop = nullptr, unsigned long long *d_inc_counts = nullptr,
-                    unsigned long long *d_partial_x = nullptr);
+                    const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2 = nullptr,
+                    unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0);
 
 }  // namespace rtmi_host
 

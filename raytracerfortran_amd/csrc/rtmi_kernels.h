@@ -41,16 +41,28 @@ typedef TraceArgsT<double> TraceArgs;
 // Incremental likelihood of the tempering sampler (fused kernel, double precision, with d_obs): a proposal changes the
 // model only from some depth `zthr` downwards, and a source above it has the stack, hence the travel time and the
 // squared residual, it has under the chain's current model -- bit for bit, so that value is taken from r2cur instead of
-// being traced again.  One record per model row, written by the sampler's step:
+// being traced again.  One record per model ROW, written by the sampler's step (a chain has one row per speculated
+// proposal, rtmi_pt_dev.hpp):
 //   zthr, dl1, dl2   the proposal being evaluated: sources with z < zthr, z != dl1, z != dl2 are unaffected (dl1 / dl2 =
 //                    the last interface of the current / the proposed model: whichLayer's special case for a source exactly
 //                    on the LAST interface, subroutineR-quiet.f90:22-30, makes such a source depend on which interface is last)
-//   pending, p*      an accepted proposal whose residuals still sit in r2prop: every launch first moves the residuals of
-//                    the sources THAT proposal affected to r2cur (each source by the thread that loads it)
+//   pending, p*      an accepted proposal of the row's CHAIN whose residuals still sit in a proposal row (pend_row): a source
+//                    THAT proposal affected has its current residual there, not in r2cur; the chain's `mover` row copies them
+//                    to r2cur (each source by the thread that loads it), the other rows of the chain only read
+//   cur_row, pend_row, prop_row   rows (of nsrc doubles) of the residual slab d_r2: the chain's current residuals, the
+//                    residuals of the pending proposal, where this row's own residuals go.  A chain's rows write a buffer
+//                    that none of them reads in the same launch (the step alternates two sets of proposal rows)
+//   n0, pn0          the handle's sources are SORTED BY DEPTH: sources [0, n0) lie above everything this proposal changes
+//                    (z < min(zthr, dl1, dl2): never loaded, their residuals are added from the cache as a prefix), sources
+//                    [0, pn0) above everything the pending proposal changed.  Conservative bounds from a depth histogram
+//                    (multiples of 64); the per-source tests above decide for the rest
 struct PtInc {
     double zthr, dl1, dl2;
     double pzthr, pdl1, pdl2;
     int pending;
+    int mover;
+    int cur_row, pend_row, prop_row;
+    int n0, pn0;
     int pad_;
 };
 
@@ -81,12 +93,14 @@ struct FusedArgsT {
                                    // out (bits 1, 2, 4) or a d_nlayers[m] was out of range (bit 8)
     int max_nlayers;               // with d_nlayers: every d_nlayers[m] must lie in [1, max_nlayers]
     int allow_skip;                // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
-    unsigned long long *d_partial_x;  // [nmodels][grid.x][4] or NULL: the SAMPLER's form of the sums -- per workgroup an exact
+    unsigned long long *d_partial_x;  // [nmodels][part_stride][4] or NULL: the SAMPLER's form of the sums -- per workgroup an exact
                                       // order-independent fixed-point sum of squared residuals (rtmi_device.hpp::Acc192: words 0, 1; 2, 3 unused)
-                                      // instead of d_partial; needs d_obs, no d_timeP, T = double, the fused kernel
+                                      // instead of d_partial; needs d_obs, no d_timeP, T = double, the fused kernel.  In this form
+                                      // THE SOURCE SET MUST BE SORTED BY DEPTH (ascending, NaN last): the kernel does not sort
     const PtInc *d_inc;            // [nmodels] or NULL: incremental likelihood (see PtInc); needs d_partial_x
-    T *d_r2cur, *d_r2prop;         // [nmodels][nsrc] squared residuals under the current model / of the proposal
-    unsigned long long *d_inc_counts;  // [nmodels][grid.x][2] or NULL: sources traced / taken from the cache, added up over the launches
+    T *d_r2;                       // residual slab of the incremental likelihood: rows of nsrc squared residuals (PtInc names the rows)
+    unsigned long long *d_inc_counts;  // [nmodels][part_stride][2] or NULL: sources traced / taken from the cache, added up over the launches
+    int part_stride;               // words of d_partial_x / d_inc_counts per model row are indexed [m][part_stride]; 0 = the launch's grid.x
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };
@@ -104,6 +118,9 @@ struct PtSweepArgs {
     unsigned int *count;   // [nchains] workgroup arrivals (gx per slot)
     unsigned int *abort_;  // [1] set when a bounded wait ran out: every workgroup leaves at its next wait
     int lds_ctl;           // set by the launcher: byte offset of the kernel's own control word in dynamic LDS
+    int nspec;             // > 0: the speculative step (rtmi_pt_dev.hpp::pt_step_spec) with this many model rows per chain; a
+                           // chain runs passes until its sweep is complete (nslots_k only bounds them), `epoch` is a tag of
+                           // the sweep (the passes of a sweep count from it, at most 4096)
 };
 
 // Arguments of the single-precision fast forward model (rtmi_f32fast.hip).  Sorted interfaces, positive velocities.

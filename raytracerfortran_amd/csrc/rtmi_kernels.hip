@@ -222,6 +222,7 @@ __device__ __forceinline__ int bin_of(int nl, int nl_max)
 #define RTMI_RK_CONV 0x80000000u      // rk: solver reported convergence
 #define RTMI_RK_SHORT 0x20000000u     // rk: Newton straight from p0 (short class of the solve queue)
 #define RTMI_RK_DONE 0x40000000u      // rk: p_final is in rp (set by the first evaluation, or when the solve loop finishes the source)
+#define RTMI_RK_SKIP 0x04000000u      // rk: (sorted source sets) a slot without a record: finished, nothing to compute or to write
 
 // One persistent workgroup per CU (blockDim = 64 x waves, up to 1024).  Workgroup b owns the 64-source
 // chunks b, b + gridDim.x, ...; per round it holds up to `slots` of their records in LDS.
@@ -239,12 +240,17 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // INC: the sampler's form of the likelihood -- squared residuals are accumulated EXACTLY (Acc192, rtmi_device.hpp), so
     // the sum does not depend on who adds what in which order, and (with a.d_inc) unaffected sources come from the cache
     constexpr bool INC = INCR && WANT_SS && !WANT_T && !WANT_P && std::is_same<T, double>::value;  // its own instantiation
+    // SORTED: the sampler's form runs over a source set that is sorted by depth (ascending, NaN last; rtmi_pt_create sorts the
+    // handle's copy once): a workgroup's records are in layer order as they are loaded -- no counting, no scan, no scatter --
+    // and the sources a proposal does not affect are a PREFIX of the set that is never loaded (PtInc::n0).
+    constexpr bool SORTED = INC;
+    const int pstride = a.part_stride ? a.part_stride : gx;  // rows of d_partial_x / d_inc_counts are [m][pstride]
     a.nlayers = a.d_nlayers ? a.d_nlayers[m] : a.nlayers;
     if (a.d_nlayers && reject_model_row<T>(a.nlayers, a.max_nlayers, a.allow_skip, a.d_status,
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
                                            (WANT_SS && !INC) ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx)) {
         if (INC && threadIdx.x == 0) {
-            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
+            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
             o[0] = o[2] = o[3] = 0ull;
             o[1] = (a.allow_skip && a.nlayers == 0) ? 0ull : RTMI_ACC_NAN;  // an unusable row: NaN, like the plain form
         }
@@ -259,10 +265,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     Acc192 acc = acc_zero();  // (INC) this thread's squared residuals
     PtInc ic = {};
     unsigned int n_cached = 0, n_traced = 0;  // this WAVE's sources (statistics of the incremental likelihood; scalar)
+    T *r2cur = nullptr, *r2pend = nullptr, *r2prop = nullptr;
+    int64_t n0 = 0;  // (SORTED) sources [0, n0) are not loaded: their residuals come from the cache
     if (inc) {
         ic = a.d_inc[m];
-        a.d_r2cur += (int64_t)m * a.nsrc;
-        a.d_r2prop += (int64_t)m * a.nsrc;
+        r2cur = a.d_r2 + (int64_t)ic.cur_row * a.nsrc;
+        r2pend = a.d_r2 + (int64_t)ic.pend_row * a.nsrc;
+        r2prop = a.d_r2 + (int64_t)ic.prop_row * a.nsrc;
+        n0 = ic.n0;
     }
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index: scalar
@@ -271,15 +281,15 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // Source data of chunk c of the round that starts at j0 (0 outside the round / the source set).  The loads of
     // a wave's next chunk are always requested before the current one is used, the very first ones before the
     // layer table is built.
-    const int64_t nchunks_all = (a.nsrc + 63) / 64;
+    const int64_t nchunks_all = (a.nsrc - n0 + 63) / 64;
     auto depth_of = [&](int64_t j0, int c) {
         const int64_t chunk = (int64_t)bx + (j0 + c) * (int64_t)gx;
-        const int64_t k = chunk * 64 + lane;
+        const int64_t k = n0 + chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_depth[k] : T(0.0);
     };
     auto offset_of = [&](int64_t j0, int c) {
         const int64_t chunk = (int64_t)bx + (j0 + c) * (int64_t)gx;
-        const int64_t k = chunk * 64 + lane;
+        const int64_t k = n0 + chunk * 64 + lane;
         return (c < slots / 64 && chunk < nchunks_all && k < a.nsrc) ? a.d_src_offset[k] : T(0.0);
     };
     // a window of PF chunks per wave is kept in flight (C2: a wave's four chunks of the round, all at once; the forms of the
@@ -287,8 +297,11 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     constexpr int PF = INC ? 1 : (WANT_SS ? 2 : RTMI_PREFETCH);
     T zw[PF], Rw[PF];
 #pragma unroll
-    for (int j = 0; j < PF; ++j)
+    for (int j = 0; j < PF; ++j) {
         zw[j] = depth_of(0, wib + j * nwib);
+        if constexpr (SORTED)
+            Rw[j] = offset_of(0, wib + j * nwib);
+    }
     const LayerTable<T> t = carve_table<TF>(lds, a.nlayers, ROWS, a.skiptab != 0);
     // DET: the records' slots decide the order of the floating-point residual sum (the batch API's logL), so the sort must
     // be the same on every run: ranks by ballots.  Every other form of the kernel (travel times only; the sampler's
@@ -332,15 +345,63 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     // live in `hist`, which is free once the records are in their slots
     unsigned long long *ch_cnt = reinterpret_cast<unsigned long long *>(hist);  // [128]
     unsigned long long *ch_start = ch_cnt + 128;                                  // [128]
-    if constexpr (!DET) {
+    // (SORTED) the control words of a round: queue head, records, the hand-over ring -- before the round's load pass
+    auto init_round_ctl = [&]() {
+        if (wib == 0) {
+            if (lane == 0) {
+                qctl[0] = 0;
+                qctl[1] = 0;
+                qctl[2] = 0;
+                qctl[3] = 0;
+                pl_ctl[0] = 0;
+                pl_ctl[1] = 0;
+                pl_ctl[2] = nwib > 4 ? nwib - 4 : 0;
+            }
+            for (int i = lane; i < RTMI_POOL; i += 64)
+                pl_ready[i] = 0;
+        }
+    };
+    if constexpr (SORTED) {
+        init_round_ctl();  // of the first round: before the barriers of stage_model
+    } else if constexpr (!DET) {
         if (threadIdx.x < 64)
             hist[threadIdx.x] = 0u;  // the bin counters of the first round: zeroed before the barriers of stage_model
+    }
+    if constexpr (SORTED) {
+        // The unaffected prefix [0, n0) of the depth-sorted set: squared residuals under the chain's current model, from the
+        // cache -- from the pending proposal's row where THAT proposal changed them (sources from pn0 on, by their depths) --
+        // and the chain's mover row brings r2cur up to date on the way.  Nothing else of these sources is ever loaded.
+        if (inc && n0 > 0) {
+            const int64_t stride = (int64_t)gx * blockDim.x;
+#pragma unroll 1
+            for (int64_t kw = (int64_t)bx * blockDim.x + wib * 64; kw < n0; kw += stride) {  // wave-uniform
+                const int64_t k = kw + lane;
+                const bool valid = k < n0;
+                bool moved = false;
+                if (valid && ic.pending && k >= ic.pn0) {
+                    const double z = (double)a.d_src_depth[k];
+                    moved = !(z < ic.pzthr && z != ic.pdl1 && z != ic.pdl2);
+                }
+                if (valid) {
+                    T r2c;
+                    if (moved) {
+                        r2c = r2pend[k];
+                        if (ic.mover)
+                            r2cur[k] = r2c;
+                    } else {
+                        r2c = r2cur[k];
+                    }
+                    acc_add_double(acc, (double)r2c);
+                }
+                n_cached += (unsigned int)__popcll(__ballot(valid));
+            }
+        }
     }
     stage_model<true>(t, a.d_vels, a.d_depths, a.nlayers);
 
     const int64_t b = bx;
     const int64_t nblocks = gx;
-    const int64_t nchunks = (a.nsrc + 63) / 64;
+    const int64_t nchunks = (a.nsrc - n0 + 63) / 64;  // (n0 = 0 but for the sampler's form: chunks of the LOADED part of the set)
     const int CH = slots / 64;
     const int nl_max = a.nlayers + 1;
 
@@ -356,175 +417,268 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
         if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
             stamps[0] = clock64();
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        uint32_t mycnt = 0;
-        if (j0 > 0) {
+        if constexpr (SORTED) {
+            // ---- a. (sorted source set) ONE load pass, no sort --------------------------------------------------------
+            // The set is sorted by depth, so this workgroup's sources -- chunks b, b + gx, ... of the loaded part, in order --
+            // come with non-decreasing layer index: the record of local source `loc` goes to slot T - 1 - loc (descending
+            // layer order, as the counting sort of the other forms leaves it).  Sources that need no record -- not affected
+            // by the proposal (residual from the cache), straight rays of the top layer (finished here) -- are the
+            // SHALLOWEST of the round, i.e. the highest slots: the round's record count is 1 + the highest slot that holds a
+            // record, and a slot below it without one (a source exactly on dl1 / dl2 has neighbours that are cached) is
+            // marked RTMI_RK_SKIP: finished, nothing to compute, nothing to write.
+            if (j0 > 0) {
 #pragma unroll
-            for (int j = 0; j < PF; ++j)
-                zw[j] = depth_of(j0, wib + j * nwib);
-            if constexpr (!DET) {
-                if (threadIdx.x < 64)
-                    hist[threadIdx.x] = 0u;  // (the round before ended with a barrier; nothing has touched hist since)
+                for (int j = 0; j < PF; ++j) {
+                    zw[j] = depth_of(j0, wib + j * nwib);
+                    Rw[j] = offset_of(j0, wib + j * nwib);
+                }
+                init_round_ctl();  // (the round before ended with a barrier)
                 __syncthreads();
             }
-        }
-        // The window of PF chunks is indexed statically (the loop over a wave's chunks is unrolled by the window):
-        // a chunk's registers are reloaded for the chunk PF steps ahead as soon as they are consumed, and no
-        // register is moved -- a move would make the compiler wait for every load in flight.
-        auto pass1 = [&](const int c, const int64_t chunk, const T z) {
-            const int64_t k = chunk * 64 + lane;
-            const bool valid = k < a.nsrc;
-            // incremental likelihood: a source the proposal does not affect is neither located nor sorted (its squared
-            // residual is added from the cache in the second pass)
-            const bool unaffected = inc && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
-            int nl = unaffected ? 1 : which_layer(t, a.nlayers, z);
-            if (!valid)
-                nl = 1;  // like a straight ray: never queued
-            const int bin = bin_of(nl, nl_max);
-            uint32_t rank = 0;  // DET: of this record among the wave's records of its bin (chunks in order, lanes in order)
-            if constexpr (!DET) {
-                if (nl > 1)
-                    rank = atomicAdd(&hist[bin], 1u);  // of this record among the workgroup's records of its bin, in no particular order
-            }
-            unsigned long long todo = DET ? __ballot(nl > 1) : 0ull;
-            while (todo) {
-                const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
-                const unsigned long long grp = __ballot(nl > 1 && bin == lb);
-                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, lb);
-                if (nl > 1 && bin == lb)
-                    rank = before + (uint32_t)__popcll(grp & lt_mask);
-                if (lane == lb)
-                    mycnt += (uint32_t)__popcll(grp);
-                todo &= ~grp;
-            }
-            tnl[c * 64 + lane] = (uint32_t)nl | (rank << 11);  // nl <= 1025, rank < 8192
-        };
-#pragma unroll 1
-        for (int cb = wib; cb < CH; cb += PF * nwib) {
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                const int c = cb + j * nwib;
-                const int64_t chunk = b + (j0 + c) * nblocks;
-                if (c < CH && chunk < nchunks) {  // wave-uniform
-                    const T z = zw[j];
-                    zw[j] = depth_of(j0, c + PF * nwib);
-                    pass1(c, chunk, z);
-                }
-            }
-        }
-        if constexpr (DET)
-            hist[wib * 64 + lane] = mycnt;
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {  // in flight during the scan
-            Rw[j] = offset_of(j0, wib + j * nwib);
-            zw[j] = depth_of(j0, wib + j * nwib);
-        }
-        __syncthreads();
-        if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
-            stamps[4] = clock64();  // depths loaded, bins counted
-        if (wib == 0) {
-            uint32_t tot = 0;
-            if constexpr (DET) {
-                for (int w = 0; w < nwib; ++w)
-                    tot += hist[w * 64 + lane];
-            } else {
-                tot = hist[lane];
-            }
-            uint32_t incl = tot;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, 64);
-                if (lane >= off)
-                    incl += o;
-            }
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t run = total - incl;  // first slot of bin `lane` when bins are laid out descending
-            if constexpr (DET) {
-                for (int w = 0; w < nwib; ++w) {
-                    const uint32_t c = hist[w * 64 + lane];
-                    hist[w * 64 + lane] = run;  // first slot of (wave w, bin lane)
-                    run += c;
-                }
-            } else {
-                hist[lane] = run;               // first slot of bin lane
-            }
-            if (lane == 0) {
-                qctl[0] = 0;
-                qctl[1] = total;
-                qctl[2] = 0;
-                qctl[3] = 0;
-                pl_ctl[0] = 0;
-                pl_ctl[1] = 0;
-                pl_ctl[2] = nwib > 4 ? nwib - 4 : 0;
-            }
-            for (int i = lane; i < RTMI_POOL; i += 64)
-                pl_ready[i] = 0;
-        }
-        __syncthreads();
-        auto pass2 = [&](const int c, const int64_t chunk, const T R, const T z) {
-            const int64_t k = chunk * 64 + lane;
-            const bool valid = k < a.nsrc;
-            const uint32_t packed = valid ? tnl[c * 64 + lane] : 1u;
-            const int nl = (int)(packed & 0x7FFu);
-            // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
-            const uint32_t pos = hist[(DET ? wib * 64 : 0) + bin_of(nl, nl_max)] + (packed >> 11);
-            // (incremental likelihood) not affected by the proposal, as in the first pass; counted per wave
-            const bool cached = inc && valid && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
-            if (inc) {
-                const unsigned long long cb = __ballot(cached), vb = __ballot(valid);
-                n_cached += (unsigned int)__popcll(cb);
-                n_traced += (unsigned int)__popcll(vb & ~cb);
-            }
-            if (valid) {
-                T r2c = T(0.0);
+            const int64_t my_left = (nchunks - b + nblocks - 1) / nblocks - j0;  // this workgroup's chunks from this round on
+            const int nmy = (int)(my_left < CH ? my_left : CH);
+            const int64_t last_ord = (nchunks - 1 - b) / nblocks;
+            const bool has_last = (nchunks - 1 - b) % nblocks == 0 && last_ord < j0 + nmy;  // the set's last (partial) chunk
+            const int T_round = 64 * nmy - (has_last ? (int)(64 * nchunks - (a.nsrc - n0)) : 0);
+            int top = 0;  // 1 + the highest slot this lane gave a record
+            auto load1 = [&](const int c, const int64_t chunk, const T R, const T z) {
+                const int64_t k = n0 + chunk * 64 + lane;
+                const bool valid = k < a.nsrc;
+                const int loc = c * 64 + lane;
+                const int pos = T_round - 1 - loc;  // valid lanes: 0 <= pos
+                // (incremental likelihood) not affected by the proposal: z above everything it changes; counted per wave
+                const bool cached = inc && valid && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
                 if (inc) {
-                    // residuals of the last accepted proposal that are still in r2prop: this source's moves to r2cur now
-                    const bool moved = ic.pending && !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
-                    if (moved) {
-                        r2c = a.d_r2prop[k];
-                        a.d_r2cur[k] = r2c;
-                    } else if (cached) {
-                        r2c = a.d_r2cur[k];
-                    }
+                    const unsigned long long cb = __ballot(cached), vb = __ballot(valid);
+                    n_cached += (unsigned int)__popcll(cb);
+                    n_traced += (unsigned int)__popcll(vb & ~cb);
                 }
-                if (cached) {
-                    if constexpr (INC)
-                        acc_add_double(acc, (double)r2c);  // not affected by the proposal: its residual under the current model
-                } else if (nl == 1) {
-                    // straight ray in the top layer (:94-97): finished here
-                    const T tt = straight_time(z, R, t.V[0]);
-                    if (WANT_T)
-                        a.d_timeP[k] = tt;
-                    if (WANT_P)
-                        a.d_p_final[k] = __builtin_nan("");
-                    if (WANT_SS) {
-                        const T r = a.d_obs[k] - tt;
-                        if constexpr (INC) {
-                            acc_add_double(acc, (double)(r * r));
-                            if (inc)
-                                a.d_r2prop[k] = r * r;
-                        } else {
-                            ss = ss + r * r;
+                const int nl = which_layer(t, a.nlayers, z);
+                T tt0 = T(0.0);
+                if (nl == 1)
+                    tt0 = straight_time(z, R, t.V[0]);  // (:94-97)
+                if (valid) {
+                    T r2c = T(0.0);
+                    if (inc) {
+                        // a source the chain's pending (accepted) proposal changed has its current residual in that proposal's
+                        // row; the chain's mover row copies it to r2cur
+                        const bool moved = ic.pending && k >= ic.pn0 &&
+                                           !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
+                        if (moved) {
+                            if (cached || ic.mover)
+                                r2c = r2pend[k];
+                            if (ic.mover)
+                                r2cur[k] = r2c;
+                        } else if (cached) {
+                            r2c = r2cur[k];
                         }
                     }
-                } else {
-                    // (the start value p0 is computed by the first-evaluation pass, from the record)
-                    rR[pos] = R;
-                    rz[pos] = z;
-                    rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
+                    if (cached) {
+                        acc_add_double(acc, (double)r2c);  // its residual under the current model
+                        rk[pos] = RTMI_RK_SKIP | RTMI_RK_DONE | (2u << RTMI_RK_NL_SHIFT);
+                    } else if (nl == 1) {
+                        const T r = a.d_obs[k] - tt0;
+                        acc_add_double(acc, (double)(r * r));
+                        if (inc)
+                            r2prop[k] = r * r;
+                        rk[pos] = RTMI_RK_SKIP | RTMI_RK_DONE | (2u << RTMI_RK_NL_SHIFT);
+                    } else {
+                        // (the start value p0 is computed by the first-evaluation pass, from the record)
+                        rR[pos] = R;
+                        rz[pos] = z;
+                        rk[pos] = (uint32_t)loc | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
+                        top = pos + 1 > top ? pos + 1 : top;
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int cb = wib; cb < CH; cb += PF * nwib) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int c = cb + j * nwib;
+                    const int64_t chunk = b + (j0 + c) * nblocks;
+                    if (c < CH && chunk < nchunks) {  // wave-uniform
+                        const T R = Rw[j], z = zw[j];
+                        Rw[j] = offset_of(j0, c + PF * nwib);
+                        zw[j] = depth_of(j0, c + PF * nwib);
+                        load1(c, chunk, R, z);
+                    }
                 }
             }
-        };
-#pragma unroll 1
-        for (int cb = wib; cb < CH; cb += PF * nwib) {
+            top = wave_max_i32(top);
+            if (lane == 0 && top > 0)
+                atomicMax(&qctl[1], (uint32_t)top);
+        } else {
+            uint32_t mycnt = 0;
+            if (j0 > 0) {
 #pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                const int c = cb + j * nwib;
-                const int64_t chunk = b + (j0 + c) * nblocks;
-                if (c < CH && chunk < nchunks) {  // wave-uniform
-                    const T R = Rw[j], z = zw[j];
-                    Rw[j] = offset_of(j0, c + PF * nwib);
-                    zw[j] = depth_of(j0, c + PF * nwib);
-                    pass2(c, chunk, R, z);
+                for (int j = 0; j < PF; ++j)
+                    zw[j] = depth_of(j0, wib + j * nwib);
+                if constexpr (!DET) {
+                    if (threadIdx.x < 64)
+                        hist[threadIdx.x] = 0u;  // (the round before ended with a barrier; nothing has touched hist since)
+                    __syncthreads();
+                }
+            }
+            // The window of PF chunks is indexed statically (the loop over a wave's chunks is unrolled by the window):
+            // a chunk's registers are reloaded for the chunk PF steps ahead as soon as they are consumed, and no
+            // register is moved -- a move would make the compiler wait for every load in flight.
+            auto pass1 = [&](const int c, const int64_t chunk, const T z) {
+                const int64_t k = chunk * 64 + lane;
+                const bool valid = k < a.nsrc;
+                // incremental likelihood: a source the proposal does not affect is neither located nor sorted (its squared
+                // residual is added from the cache in the second pass)
+                const bool unaffected = inc && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+                int nl = unaffected ? 1 : which_layer(t, a.nlayers, z);
+                if (!valid)
+                    nl = 1;  // like a straight ray: never queued
+                const int bin = bin_of(nl, nl_max);
+                uint32_t rank = 0;  // DET: of this record among the wave's records of its bin (chunks in order, lanes in order)
+                if constexpr (!DET) {
+                    if (nl > 1)
+                        rank = atomicAdd(&hist[bin], 1u);  // of this record among the workgroup's records of its bin, in no particular order
+                }
+                unsigned long long todo = DET ? __ballot(nl > 1) : 0ull;
+                while (todo) {
+                    const int lb = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);  // scalar
+                    const unsigned long long grp = __ballot(nl > 1 && bin == lb);
+                    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, lb);
+                    if (nl > 1 && bin == lb)
+                        rank = before + (uint32_t)__popcll(grp & lt_mask);
+                    if (lane == lb)
+                        mycnt += (uint32_t)__popcll(grp);
+                    todo &= ~grp;
+                }
+                tnl[c * 64 + lane] = (uint32_t)nl | (rank << 11);  // nl <= 1025, rank < 8192
+            };
+#pragma unroll 1
+            for (int cb = wib; cb < CH; cb += PF * nwib) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int c = cb + j * nwib;
+                    const int64_t chunk = b + (j0 + c) * nblocks;
+                    if (c < CH && chunk < nchunks) {  // wave-uniform
+                        const T z = zw[j];
+                        zw[j] = depth_of(j0, c + PF * nwib);
+                        pass1(c, chunk, z);
+                    }
+                }
+            }
+            if constexpr (DET)
+                hist[wib * 64 + lane] = mycnt;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {  // in flight during the scan
+                Rw[j] = offset_of(j0, wib + j * nwib);
+                zw[j] = depth_of(j0, wib + j * nwib);
+            }
+            __syncthreads();
+            if (DIAG && stamps && j0 == 0 && threadIdx.x == 0)
+                stamps[4] = clock64();  // depths loaded, bins counted
+            if (wib == 0) {
+                uint32_t tot = 0;
+                if constexpr (DET) {
+                    for (int w = 0; w < nwib; ++w)
+                        tot += hist[w * 64 + lane];
+                } else {
+                    tot = hist[lane];
+                }
+                uint32_t incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(incl, off, 64);
+                    if (lane >= off)
+                        incl += o;
+                }
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t run = total - incl;  // first slot of bin `lane` when bins are laid out descending
+                if constexpr (DET) {
+                    for (int w = 0; w < nwib; ++w) {
+                        const uint32_t c = hist[w * 64 + lane];
+                        hist[w * 64 + lane] = run;  // first slot of (wave w, bin lane)
+                        run += c;
+                    }
+                } else {
+                    hist[lane] = run;               // first slot of bin lane
+                }
+                if (lane == 0) {
+                    qctl[0] = 0;
+                    qctl[1] = total;
+                    qctl[2] = 0;
+                    qctl[3] = 0;
+                    pl_ctl[0] = 0;
+                    pl_ctl[1] = 0;
+                    pl_ctl[2] = nwib > 4 ? nwib - 4 : 0;
+                }
+                for (int i = lane; i < RTMI_POOL; i += 64)
+                    pl_ready[i] = 0;
+            }
+            __syncthreads();
+            auto pass2 = [&](const int c, const int64_t chunk, const T R, const T z) {
+                const int64_t k = chunk * 64 + lane;
+                const bool valid = k < a.nsrc;
+                const uint32_t packed = valid ? tnl[c * 64 + lane] : 1u;
+                const int nl = (int)(packed & 0x7FFu);
+                // slot = first slot of (this wave, the record's bin) + the record's rank there (counted in the first pass)
+                const uint32_t pos = hist[(DET ? wib * 64 : 0) + bin_of(nl, nl_max)] + (packed >> 11);
+                // (incremental likelihood) not affected by the proposal, as in the first pass; counted per wave
+                const bool cached = inc && valid && (double)z < ic.zthr && (double)z != ic.dl1 && (double)z != ic.dl2;
+                if (inc) {
+                    const unsigned long long cb = __ballot(cached), vb = __ballot(valid);
+                    n_cached += (unsigned int)__popcll(cb);
+                    n_traced += (unsigned int)__popcll(vb & ~cb);
+                }
+                if (valid) {
+                    T r2c = T(0.0);
+                    if (inc) {
+                        // residuals of the last accepted proposal that are still in r2prop: this source's moves to r2cur now
+                        const bool moved = ic.pending && !((double)z < ic.pzthr && (double)z != ic.pdl1 && (double)z != ic.pdl2);
+                        if (moved) {
+                            r2c = r2pend[k];
+                            r2cur[k] = r2c;
+                        } else if (cached) {
+                            r2c = r2cur[k];
+                        }
+                    }
+                    if (cached) {
+                        if constexpr (INC)
+                            acc_add_double(acc, (double)r2c);  // not affected by the proposal: its residual under the current model
+                    } else if (nl == 1) {
+                        // straight ray in the top layer (:94-97): finished here
+                        const T tt = straight_time(z, R, t.V[0]);
+                        if (WANT_T)
+                            a.d_timeP[k] = tt;
+                        if (WANT_P)
+                            a.d_p_final[k] = __builtin_nan("");
+                        if (WANT_SS) {
+                            const T r = a.d_obs[k] - tt;
+                            if constexpr (INC) {
+                                acc_add_double(acc, (double)(r * r));
+                                if (inc)
+                                    r2prop[k] = r * r;
+                            } else {
+                                ss = ss + r * r;
+                            }
+                        }
+                    } else {
+                        // (the start value p0 is computed by the first-evaluation pass, from the record)
+                        rR[pos] = R;
+                        rz[pos] = z;
+                        rk[pos] = (uint32_t)(c * 64 + lane) | ((uint32_t)nl << RTMI_RK_NL_SHIFT);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int cb = wib; cb < CH; cb += PF * nwib) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int c = cb + j * nwib;
+                    const int64_t chunk = b + (j0 + c) * nblocks;
+                    if (c < CH && chunk < nchunks) {  // wave-uniform
+                        const T R = Rw[j], z = zw[j];
+                        Rw[j] = offset_of(j0, c + PF * nwib);
+                        zw[j] = depth_of(j0, c + PF * nwib);
+                        pass2(c, chunk, R, z);
+                    }
                 }
             }
         }
@@ -545,11 +699,12 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
             Lane<T> s;
             const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
             const int nl = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK);
-            const T Rq = valid ? rR[q] : T(1.0), zq = valid ? rz[q] : T(1.0);
-            const T p0 = initial_p0(t, nl - 1, Rq, zq, valid);  // GetPTime's head (:112-133)
+            const bool rec = valid && !(SORTED && (key & RTMI_RK_SKIP));  // (a slot without a record carries no source data)
+            const T Rq = rec ? rR[q] : T(1.0), zq = rec ? rz[q] : T(1.0);
+            const T p0 = initial_p0(t, nl - 1, Rq, zq, rec);  // GetPTime's head (:112-133)
             lane_setup(s, t, nl - 1, Rq, zq);
             lane_start(s, p0);
-            const bool live = valid && (p0 == p0);  // NaN p0: the reference never returns -> -999
+            const bool live = rec && (p0 == p0);  // NaN p0: the reference never returns -> -999
             if (!live)
                 s.st = ST_DONE;
             const int nfw = wave_max_i32(live ? s.nfull : 0);
@@ -562,7 +717,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 if (!live)
                     s = keep;
             }
-            if (valid) {
+            if (rec) {
                 uint32_t k2 = key;
                 if (s.st == ST_DONE) {
                     rp[q] = s.x;
@@ -987,15 +1142,16 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                     progress = true;
                     const uint32_t key = valid ? rk[q] : (2u << RTMI_RK_NL_SHIFT);
                     const int il = (int)((key >> RTMI_RK_NL_SHIFT) & RTMI_RK_NL_MASK) - 1;
-                    const T p = valid ? rp[q] : T(0.0);
-                    const T z = valid ? rz[q] : T(1.0);
-                    const int nfw = wave_max_i32(valid ? il : 0);
-                    T tt = travel_time(t, p, il, nfw, il, z, valid);
+                    const bool rec = valid && !(SORTED && (key & RTMI_RK_SKIP));
+                    const T p = rec ? rp[q] : T(0.0);
+                    const T z = rec ? rz[q] : T(1.0);
+                    const int nfw = wave_max_i32(rec ? il : 0);
+                    T tt = travel_time(t, p, il, nfw, il, z, rec);
                     if (!(key & RTMI_RK_CONV))
                         tt = -T(999.0);
-                    if (valid) {
+                    if (rec) {
                         const int loc = (int)(key & RTMI_RK_LOC_MASK);
-                        const int64_t k = (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
+                        const int64_t k = n0 + (b + (j0 + (loc >> 6)) * nblocks) * 64 + (loc & 63);
                         if (WANT_T)
                             a.d_timeP[k] = tt;
                         if (WANT_P)
@@ -1005,7 +1161,7 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                             if constexpr (INC) {
                                 acc_add_double(acc, (double)(r * r));
                                 if (inc)
-                                    a.d_r2prop[k] = r * r;
+                                    r2prop[k] = r * r;
                             } else {
                                 rR[q] = r * r;  // the record's R is not needed any more
                             }
@@ -1065,13 +1221,13 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 tr += wx[4 * w + 2];
                 ca += wx[4 * w + 3];
             }
-            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * gx + bx);
+            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
             o[0] = tot.w0;
             o[1] = tot.w1;
             o[2] = 0ull;
             o[3] = 0ull;
             if (counting) {
-                unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * gx + bx);
+                unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride + bx);
                 oc[0] += tr;
                 oc[1] += ca;
             }
@@ -1160,6 +1316,111 @@ __device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chai
     } else if (threadIdx.x < 64) {
         rtmi_pt_dev::pt_step_group<64>(d, chain, decide, sigma, propose, ivo, ipar);
     }
+}
+
+__device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int chain, int begin, int wg_total)
+{
+    const rtmi_pt_dev::PtDev d = *dp;
+    if (d.K <= 16) {
+        if (threadIdx.x < 16)
+            rtmi_pt_dev::pt_step_spec<16>(d, chain, begin, 0, wg_total);
+    } else if (d.K <= 32) {
+        if (threadIdx.x < 32)
+            rtmi_pt_dev::pt_step_spec<32>(d, chain, begin, 0, wg_total);
+    } else if (threadIdx.x < 64) {
+        rtmi_pt_dev::pt_step_spec<64>(d, chain, begin, 0, wg_total);
+    }
+}
+
+// The speculative form of the persistent sweep (rtmi_pt_dev.hpp::pt_step_spec): a chain's gx workgroups run PASSES until the
+// chain's sweep is complete.  Per pass the leading workgroup takes the step -- the decisions of the window evaluated in the
+// pass before, the sigma move once every slot is decided, the next window of up to nspec proposals -- and publishes it; the
+// chain's workgroups then deal themselves to the rows that go through the likelihood (workgroup w evaluates the a-th such
+// row, a = w mod nact, as workgroup w / nact of ceil((gx - a) / nact): the sums are exact, so how many workgroups add a row
+// up changes nothing), write their sums and arrive.  A window of proposals that all lie below the deepest source needs no
+// pass at all: the leading workgroup takes the next step at once.
+template <int TF, bool INCR>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_spec_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, PtSweepArgs w)
+{
+    using namespace rtmi_pt_dev;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    int *const d_status = a.d_status;
+    volatile int *ctl = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_raw) + w.lds_ctl);  // past the likelihood's LDS: [0] go on, [1] done
+    const int gx = w.gx;
+    int chain, row;
+    if (w.xcd_map) {
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        chain = xcd * (w.nchains >> 3) + loc / gx;
+        row = loc % gx;
+    } else {
+        chain = blockIdx.x / gx;
+        row = blockIdx.x % gx;
+    }
+    volatile unsigned int *flag = w.flag + chain, *count = w.count + chain, *abort_word = w.abort_;
+    const unsigned int count_base = __hip_atomic_load((unsigned int *)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int D = w.nspec;
+    const int max_pass = 2 * w.nslots_k + 2;  // a pass retires at least one slot of the chain
+#pragma unroll 1
+    for (int pass = 0; pass <= max_pass; ++pass) {
+        const unsigned int target = w.epoch + (unsigned int)pass + 1u;
+        if (row == 0) {
+            if (threadIdx.x < 64) {
+                int begin = pass == 0 ? 1 : 0, guard = 0;
+                // steps without a likelihood pass in between: windows whose proposals affect no source
+#pragma unroll 1
+                for (;;) {
+                    pt_step_spec_call(dp, chain, begin, gx);
+                    __threadfence();  // the rows are out before the flag; and this workgroup (one L1) reads them afresh, too
+                    __builtin_amdgcn_s_dcache_inv();  // ... and so does a step that follows at once (the chain's words are wave-uniform: scalar loads)
+                    begin = 0;
+                    const int fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fin_ || nact_ > 0 || ++guard > 4 * RTMI_PT_MAX_K)
+                        break;
+                }
+            }
+            __builtin_amdgcn_s_dcache_inv();
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store((unsigned int *)flag, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0)
+                ctl[0] = pt_wait_reached(flag, target, abort_word, d_status) ? 1 : 0;
+            __syncthreads();
+            if (!ctl[0])
+                return;
+            __builtin_amdgcn_s_dcache_inv();
+        }
+        // the chain's state after the step (written before the flag, read after it)
+        const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int nact = __builtin_amdgcn_readfirstlane(__hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (fin || nact <= 0) {
+            if (!fin && threadIdx.x == 0 && d_status)
+                atomicOr(d_status, 16);  // never expected: the leading workgroup's guard ran out
+            return;  // the sweep of this chain is complete
+        }
+        {
+            const int ai = row % nact, sub = row / nact, nw = (gx - ai + nact - 1) / nact;
+            const int e = __builtin_amdgcn_readfirstlane(dp->alist[chain * D + ai]);
+            fused_body<double, false, false, true, false, TF, INCR, true>(a, chain * D + e, sub, nw, reinterpret_cast<double *>(lds_raw));
+        }
+        __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
+        if (threadIdx.x == 0) {
+            __threadfence();
+            __hip_atomic_fetch_add((unsigned int *)count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (row == 0)
+                ctl[0] = pt_wait_reached(count, count_base + (unsigned int)(pass + 1) * (unsigned int)gx, abort_word, d_status) ? 1 : 0;
+        }
+        if (row == 0) {
+            __syncthreads();
+            if (!ctl[0])
+                return;
+            __builtin_amdgcn_s_dcache_inv();
+        }
+    }
+    // never expected: a chain that is not complete after 2 k + 2 passes
+    if (threadIdx.x == 0 && d_status)
+        atomicOr(d_status, 16);
 }
 
 template <int TF, bool INCR>
@@ -1610,8 +1871,19 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
-    const int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
-                                       &a.slots, &lds_bytes);
+    int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
+                                 &a.slots, &lds_bytes);
+    if (ws.nspec > 0 && gx >= 1) {
+        // speculative step: a row is evaluated by as few as floor(gx / nspec) of the chain's workgroups -- the record area is
+        // sized for that share (a larger share would take several rounds of it)
+        const int nw_min = gx / ws.nspec > 0 ? gx / ws.nspec : 1;
+        int threads2 = 0;
+        const int g2 = rtmi_fused_geometry(a.nsrc, max_nlayers, (nchains * gx + nw_min - 1) / nw_min, num_cus, waves_per_simd,
+                                           (int)sizeof(double), &threads2, &a.slots, &lds_bytes);
+        (void)g2;
+        if (threads2 > threads)
+            threads = threads2;
+    }
     static const bool verbose = getenv("RTMI_PT_VERBOSE") != nullptr;  // read once
     ws.lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
     lds_bytes = (size_t)ws.lds_ctl + 16;
@@ -1629,7 +1901,10 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
         a.rows = 0;
     const void *fns[2][2] = {{reinterpret_cast<const void *>(&pt_sweep_kernel<0, false>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, false>)},
                              {reinterpret_cast<const void *>(&pt_sweep_kernel<0, true>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, true>)}};
-    const void *fn = fns[a.d_partial_x ? 1 : 0][a.rows];
+    const void *fns_spec[2] = {reinterpret_cast<const void *>(&pt_sweep_spec_kernel<0, true>), reinterpret_cast<const void *>(&pt_sweep_spec_kernel<1, true>)};
+    if (ws.nspec > 0 && !a.d_partial_x)
+        return hipErrorInvalidValue;  // (the speculative step needs the exact sums)
+    const void *fn = ws.nspec > 0 ? fns_spec[a.rows] : fns[a.d_partial_x ? 1 : 0][a.rows];
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
         return e;

@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -53,6 +54,9 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
 // Working arrays of pt_pack_current_kernel (one thread per chain) live in LDS, not in private (scratch) memory: the
 // rules index them dynamically.  Layout: thread t owns [t * stride, (t + 1) * stride).
 #define PT_BLOCK 64
+#ifndef RTMI_PT_SPECULATE_DEFAULT
+#define RTMI_PT_SPECULATE_DEFAULT 4  // model rows per chain of the speculative step (RTMI_PT_SPECULATE overrides; 0 = one-at-a-time step)
+#endif
 
 // pt_step_kernel: the sampler's step (rtmi_pt_dev.hpp::pt_step_group) for every chain, one group of G lanes per chain.
 template <int G>
@@ -65,7 +69,18 @@ __global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_kernel(PtDev d, int d
     pt_step_group<G>(d, c, decide, sigma, propose, ivo, ipar);
 }
 
-// The current state of every chain as batch rows (rtmi_pt_evaluate).
+// The speculative step (rtmi_pt_dev.hpp::pt_step_spec): a window of up to d.nspec proposals per chain and pass.
+template <int G>
+__global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_spec_kernel(PtDev d, int begin, int eval)
+{
+    constexpr int CPB = PT_STEP_THREADS / G;  // chains per block
+    const int c = blockIdx.x * CPB + threadIdx.x / G;
+    if (c >= d.nchains)
+        return;
+    pt_step_spec<G>(d, c, begin, eval, 0);
+}
+
+// The current state of every chain as batch rows (rtmi_pt_evaluate): row chain * nspec, evaluated in full.
 __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
 {
     extern __shared__ __attribute__((aligned(16))) double pt_lds[];
@@ -79,10 +94,31 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
     load_nodes(d.z + (size_t)c * d.K, qz, k);
     load_nodes(d.v + (size_t)c * d.K, qv, k);
     R::sorted_order(qz, k, ord);
-    d.NL[c] = R::pack_model(qz, qv, k, ord, d.V + (size_t)c * d.ld_model, d.D + (size_t)c * d.ld_model);
-    d.pactive[c] = 2;
-    d.inc[c].zthr = -INFINITY;  // every source is evaluated (and the residual cache filled)
-    d.inc[c].dl1 = d.inc[c].dl2 = 0.0;
+    const int m = c * d.nspec;
+    d.NL[m] = R::pack_model(qz, qv, k, ord, d.V + (size_t)m * d.ld_model, d.D + (size_t)m * d.ld_model);
+    d.pactive[m] = 2;
+    rtmi::PtInc *o = d.inc + m;
+    o->zthr = -INFINITY;  // every source is evaluated (and the residual cache filled)
+    o->dl1 = o->dl2 = 0.0;
+    o->n0 = 0;
+    if (d.nspec > 1 || d.spec_step) {
+        // the window of the speculative step: one entry, the chain's state; the other rows are inactive
+        for (int e = 1; e < d.nspec; ++e)
+            d.NL[m + e] = 0;
+        d.nwin[c] = 1;
+        d.nact[c] = 1;
+        d.alist[m] = 0;
+        d.rowwg[m] = d.gx_launch;
+        o->pzthr = d.pend_z[3 * c + 0];
+        o->pdl1 = d.pend_z[3 * c + 1];
+        o->pdl2 = d.pend_z[3 * c + 2];
+        o->pending = d.pend_i[4 * c + 0];
+        o->pend_row = d.pend_i[4 * c + 1];
+        o->pn0 = d.pend_i[4 * c + 2];
+        o->mover = 1;
+        o->cur_row = c;
+        o->prop_row = d.nchains + (d.wbuf[c] * d.nchains + c) * d.nspec;
+    }
 }
 
 // Temperature exchange: logL, levels and the ladder are staged in LDS, thread 0 runs the shared deterministic pairing
@@ -203,6 +239,15 @@ struct rtmi_pt {
     // source sets small enough for the plain kernel, whose sums are doubles in d_partial
     unsigned long long *d_partial_x = nullptr;   // [nchains][gx][4]
     bool incremental = true;         // RTMI_PT_INCREMENTAL=0: every proposal is evaluated over all sources
+    // speculative proposals (rtmi_pt_dev.hpp::pt_step_spec): nspec model rows per chain; spec = the speculative step is in use
+    int nspec = 1, nrows = 0;
+    bool spec = false;
+    int gx_launch = 0;               // workgroups per row of the per-slot engine's batched launch
+    int *d_cdf = nullptr;            // depth histogram of the (sorted) source set
+    int *d_spec_i32 = nullptr;       // cur | fin | nwin | wend | winv | nact | wbuf | pend_i[4] (per chain), pslot | pinv | rowwg | alist (per row)
+    unsigned long long *d_spec_u64 = nullptr;  // wctr (per chain), pctr (per row)
+    double *d_pend_z = nullptr;      // [nchains][3]
+    std::vector<rtmi::PtInc> inc0;   // (one-at-a-time step) the rows of the residual slab never change: a chain's record as reset by rtmi_pt_set_chain
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
     int64_t launches = 0, models = 0;
@@ -229,28 +274,62 @@ void launch_step(rtmi_pt *h, int decide, int sigma, int propose, int ivo, int ip
         hipLaunchKernelGGL(pt_step_kernel<64>, g, b, 0, h->stream, h->d, decide, sigma, propose, ivo, ipar);
 }
 
+// pt_step_spec_kernel, likewise
+void launch_step_spec(rtmi_pt *h, int begin, int eval)
+{
+    const int G = h->K <= 16 ? 16 : (h->K <= 32 ? 32 : 64);
+    const int cpb = PT_STEP_THREADS / G;
+    const dim3 g((h->nchains + cpb - 1) / cpb), b(PT_STEP_THREADS);
+    if (G == 16)
+        hipLaunchKernelGGL(pt_step_spec_kernel<16>, g, b, 0, h->stream, h->d, begin, eval);
+    else if (G == 32)
+        hipLaunchKernelGGL(pt_step_spec_kernel<32>, g, b, 0, h->stream, h->d, begin, eval);
+    else
+        hipLaunchKernelGGL(pt_step_spec_kernel<64>, g, b, 0, h->stream, h->d, begin, eval);
+}
+
+// the batched likelihood over the handle's model rows (nchains x nspec; rows without a proposal are inactive)
 int launch_likelihood(rtmi_pt *h)
 {
     if ((h->d_partial_x != nullptr) != batch_is_fused(h->nsrc))
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt: the kernel path was changed (rtmi_set_option \"path\") while a sampler handle exists");
     int gx = 0;
     const size_t n = (size_t)h->nsrc;
-    const size_t r2n = (size_t)h->nchains * n;
-    int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
+    int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nrows, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                           nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream,
-                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr, h->d_inc_counts,
-                          h->d_partial_x);
+                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride);
     if (rc)
         return rc;
-    if (gx != h->d.gx)
+    if (gx != h->gx_launch)
         return fail(RTMI_ERR_HIP, "rtmi_pt: launch geometry changed (%d workgroups per model, handle sized for %d); do not "
-                                  "change the scheduling knobs while a handle exists", gx, h->d.gx);
+                                  "change the scheduling knobs while a handle exists", gx, h->gx_launch);
+    return RTMI_OK;
+}
+
+// One sweep of the speculative step as per-slot launches: a pass = the step (decide the window of the pass before,
+// propose the next one) + the batched likelihood over every chain's rows.  A chain retires at least one slot per pass,
+// so 2 x nslots_k passes complete every chain; a chain that is done early (most are: a pass retires two to three slots)
+// proposes nothing, its rows are inactive and their workgroups leave at once.  The step after the last pass decides the
+// last window and makes the sigma move of the chains that still have it to make.
+int enqueue_sweep_spec(rtmi_pt *h, int nslots_k)
+{
+    const int npass = 2 * nslots_k;
+    for (int p = 0; p < npass; ++p) {
+        launch_step_spec(h, p == 0 ? 1 : 0, 0);
+        const int rc = launch_likelihood(h);
+        if (rc)
+            return rc;
+    }
+    launch_step_spec(h, 0, 0);
+    HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
 
 // One sweep with `nslots_k` node slots enqueued on the handle's stream (directly, or into a capture).
 int enqueue_sweep(rtmi_pt *h, int nslots_k)
 {
+    if (h->spec)
+        return enqueue_sweep_spec(h, nslots_k);
     launch_step(h, PT_NONE, 0, PT_BD, 0, 0);
     int rc = launch_likelihood(h);
     if (rc)
@@ -306,12 +385,12 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         w.count = h->d_sync + h->nchains;
         w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
         const size_t n = (size_t)h->nsrc;
-        const size_t r2n = (size_t)h->nchains * n;
+        w.nspec = h->spec ? h->nspec : 0;
         if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                             h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream,
-                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_r2 ? h->d_r2 + r2n : nullptr,
-                            h->d_inc_counts, h->d_partial_x) == RTMI_OK) {
-            h->epoch += 2u * (unsigned int)ks;
+                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x,
+                            h->d.part_stride) == RTMI_OK) {
+            h->epoch += h->spec ? 4096u : 2u * (unsigned int)ks;  // (spec: passes of a sweep are counted from a tag of its own)
             h->launches += 1;
             return RTMI_OK;
         }
@@ -319,7 +398,7 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         h->engine = 0;
         closer.e = nullptr;
     }
-    h->launches += 2 * ks;
+    h->launches += 2 * ks;  // likelihood launches (spec: passes; most of the later ones find every row inactive)
     if (!h->use_graph) {
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
@@ -436,28 +515,49 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         h->use_persistent = strcmp(e, "0") != 0;
         h->engine = h->use_persistent ? 1 : 0;
     }
-    const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n;
-    const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
     const bool fused_path = batch_is_fused(c.set_n);  // which kernel the handle's likelihood launches will take
-    const size_t nf64 = 4 * nc * K + 5 * nc + 2 * nc * ldm;
-    const size_t ni32 = 4 * nc;
+    // Speculative proposals (rtmi_pt_dev.hpp::pt_step_spec) need the exact sums of the fused kernel's sampler form: with them
+    // a chain is bit for bit the chain of the one-at-a-time step.  RTMI_PT_SPECULATE = rows per chain (0: the one-at-a-time
+    // step pt_step_group).
+    int want_spec = RTMI_PT_SPECULATE_DEFAULT;
+    if (const char *e = getenv("RTMI_PT_SPECULATE"))
+        want_spec = atoi(e);
+    if (want_spec > PT_SPEC_MAX)
+        want_spec = PT_SPEC_MAX;
+    h->spec = fused_path && want_spec >= 1;
+    h->nspec = h->spec ? want_spec : 1;
+    h->nrows = nchains * h->nspec;
+    const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n, nr = (size_t)h->nrows;
+    const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);     // workgroups per CHAIN (persistent engine)
+    h->gx_launch = batch_grid_x(h->nrows, h->max_nl, c.set_n, c.cus);    // workgroups per ROW of the batched launch
+    const int pstride = gx > h->gx_launch ? gx : h->gx_launch;
+    const size_t nf64 = 2 * nc * K + 2 * nr * K + 4 * nc + nr + 2 * nr * ldm;
+    const size_t ni32 = nc + 3 * nr;
+    const size_t nsi32 = 11 * nc + 4 * nr, nsu64 = nc + nr;
+    const int ncdf = 4096;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void **)&h->d_set, 3 * n * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_f64, nf64 * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_i32, ni32 * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_u64, 9 * nc * sizeof(unsigned long long)) == hipSuccess &&
-              hipMalloc((void **)&h->d_partial, nc * (size_t)gx * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_partial, nr * (size_t)pstride * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_logpk, ((size_t)prior->kmax + 2) * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_sync, (2 * nc + 1) * sizeof(unsigned int)) == hipSuccess &&
-              hipMalloc((void **)&h->d_inc, nc * sizeof(rtmi::PtInc)) == hipSuccess &&
+              hipMalloc((void **)&h->d_inc, nr * sizeof(rtmi::PtInc)) == hipSuccess &&
               hipMalloc((void **)&h->d_cache_valid, nc * sizeof(int)) == hipSuccess &&
-              (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nc * (size_t)gx * sizeof(unsigned long long)) == hipSuccess);
-    // The residual cache of the incremental likelihood (2 x nchains x nsrc doubles) and its counters exist only where they
-    // are read: the incremental likelihood switched on AND the fused kernel's sampler form (exact sums).  A cache that does
-    // not fit (many chains over 1e6+ sources) is not an error: the handle evaluates every proposal in full instead.
+              hipMalloc((void **)&h->d_spec_i32, nsi32 * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_spec_u64, nsu64 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void **)&h->d_pend_z, 3 * nc * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_cdf, (size_t)ncdf * sizeof(int)) == hipSuccess &&
+              (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nr * (size_t)pstride * sizeof(unsigned long long)) == hipSuccess);
+    // The residual cache of the incremental likelihood (the chains' current residuals + one row per model row, twice with the
+    // speculative step: the two sets alternate) and its counters exist only where they are read: the incremental likelihood
+    // switched on AND the fused kernel's sampler form (exact sums).  A cache that does not fit (many chains over 1e6+ sources)
+    // is not an error: the handle evaluates every proposal in full instead.
+    const size_t r2rows = h->spec ? nc + 2 * nr : 2 * nc;
     if (ok && h->incremental && fused_path) {
-        if (hipMalloc((void **)&h->d_r2, 2 * nc * n * sizeof(double)) != hipSuccess ||
-            hipMalloc((void **)&h->d_inc_counts, 2 * nc * (size_t)gx * sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc((void **)&h->d_r2, r2rows * n * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&h->d_inc_counts, 2 * nr * (size_t)pstride * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipGetLastError();
             if (h->d_r2)
                 (void)hipFree(h->d_r2);
@@ -465,25 +565,83 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
             h->d_inc_counts = nullptr;
             h->incremental = false;
             fprintf(stderr, "rtmi_pt_create: no room for the residual cache (%.1f GiB): every proposal is evaluated over all sources\n",
-                    (double)(2 * nc * n * sizeof(double)) / (1024.0 * 1024.0 * 1024.0));
+                    (double)(r2rows * n * sizeof(double)) / (1024.0 * 1024.0 * 1024.0));
         }
     } else {
         h->incremental = false;
     }
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
-             hipMemsetAsync(h->d_inc, 0, nc * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_inc, 0, nr * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_cache_valid, 0, nc * sizeof(int), h->stream) == hipSuccess &&
-             (!h->d_inc_counts || hipMemsetAsync(h->d_inc_counts, 0, 2 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess) &&
-             (!h->d_partial_x || hipMemsetAsync(h->d_partial_x, 0, 4 * nc * (size_t)gx * sizeof(unsigned long long), h->stream) == hipSuccess) &&
-             (!h->d_r2 || hipMemsetAsync(h->d_r2, 0, 2 * nc * n * sizeof(double), h->stream) == hipSuccess);
-    if (ok) {
-        // the handle OWNS its source set: a later rtmi_set_sources does not retarget it
-        ok = hipMemcpyAsync(h->d_set, c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_spec_i32, 0, nsi32 * sizeof(int), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_spec_u64, 0, nsu64 * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_pend_z, 0, 3 * nc * sizeof(double), h->stream) == hipSuccess &&
+             (!h->d_inc_counts || hipMemsetAsync(h->d_inc_counts, 0, 2 * nr * (size_t)pstride * sizeof(unsigned long long), h->stream) == hipSuccess) &&
+             (!h->d_partial_x || hipMemsetAsync(h->d_partial_x, 0, 4 * nr * (size_t)pstride * sizeof(unsigned long long), h->stream) == hipSuccess) &&
+             (!h->d_r2 || hipMemsetAsync(h->d_r2, 0, r2rows * n * sizeof(double), h->stream) == hipSuccess) &&
              hipMemsetAsync(h->d_f64, 0, nf64 * sizeof(double), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_i32, 0, ni32 * sizeof(int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_u64, 0, 9 * nc * sizeof(unsigned long long), h->stream) == hipSuccess &&
-             hipMemsetAsync(h->d_partial, 0, nc * (size_t)gx * sizeof(double), h->stream) == hipSuccess;
+             hipMemsetAsync(h->d_partial, 0, nr * (size_t)pstride * sizeof(double), h->stream) == hipSuccess;
+    PtDev &d = h->d;
+    memset(&d, 0, sizeof d);
+    if (ok) {
+        // The handle OWNS its source set (a later rtmi_set_sources does not retarget it) -- and, where its likelihood is the
+        // fused kernel's sampler form, keeps it SORTED BY DEPTH (NaN last): the sampler only ever asks for sums over the
+        // sources, which do not depend on their order (exact sums), and in depth order the sources a proposal does not affect
+        // are a prefix of the set, a workgroup's records are in layer order as they are loaded (no sort in the kernel).
+        std::vector<double> set(3 * n);
+        ok = hipMemcpy(set.data(), c.d_set, 3 * n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        std::vector<int> cdf((size_t)ncdf, 0);
+        double zmax = -INFINITY, zmin = INFINITY;
+        for (size_t i = 0; i < n; ++i) {
+            const double z = set[n + i];
+            if (z == z && z > zmax)
+                zmax = z;
+            if (z == z && z < zmin)
+                zmin = z;
+        }
+        d.zmax_src = zmax;  // the deepest source: proposals that change the model only below it need no launch
+        d.cdf_z0 = zmin;
+        d.cdf_inv = (zmax > zmin && zmax - zmin < INFINITY) ? (double)ncdf / (zmax - zmin) : 0.0;
+        if (ok && fused_path) {
+            std::vector<size_t> perm(n);
+            for (size_t i = 0; i < n; ++i)
+                perm[i] = i;
+            const double *zs = set.data() + n;
+            std::stable_sort(perm.begin(), perm.end(), [zs](size_t a, size_t b) {
+                const double za = zs[a], zb = zs[b];
+                if (za != za || zb != zb)
+                    return zb != zb && za == za;  // NaN after every number
+                return za < zb;
+            });
+            std::vector<double> sorted(3 * n);
+            for (size_t i = 0; i < n; ++i)
+                for (int a = 0; a < 3; ++a)
+                    sorted[(size_t)a * n + i] = set[(size_t)a * n + perm[i]];
+            set.swap(sorted);
+            // depth histogram: cdf[g] = sources whose bin is below g (rtmi_pt_dev.hpp::prefix_above uses the same formula)
+            if (d.cdf_inv > 0.0) {
+                std::vector<int> cnt((size_t)ncdf + 1, 0);
+                for (size_t i = 0; i < n; ++i) {
+                    const double z = set[n + i];
+                    if (z != z)
+                        continue;
+                    const double t = (z - d.cdf_z0) * d.cdf_inv;
+                    const int g = t >= (double)(ncdf - 1) ? ncdf - 1 : (t > 0.0 ? (int)t : 0);
+                    cnt[(size_t)g + 1] += 1;
+                }
+                int run = 0;
+                for (int g = 0; g < ncdf; ++g) {
+                    run += cnt[(size_t)g];
+                    cdf[(size_t)g] = run;
+                }
+            }
+        }
+        ok = ok && hipMemcpyAsync(h->d_set, set.data(), 3 * n * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipMemcpyAsync(h->d_cdf, cdf.data(), (size_t)ncdf * sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipStreamSynchronize(h->stream) == hipSuccess;
     }
     std::vector<double> lpk((size_t)prior->kmax + 2, 0.0);
     for (int k = 1; k <= prior->kmax + 1; ++k)
@@ -492,8 +650,6 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     if (ok)
         ok = hipMemcpyAsync(h->d_logpk, lpk.data(), lpk.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) ==
              hipSuccess;
-    PtDev &d = h->d;
-    memset(&d, 0, sizeof d);
     d.nchains = nchains;
     d.K = h->K;
     d.ld_model = ld_model;
@@ -503,23 +659,30 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.seed = seed;
     d.stream_id = (uint32_t)stream_id;
     d.logpk = h->d_logpk;
+    d.nsrc = c.set_n;
+    d.cdf = (fused_path && d.cdf_inv > 0.0) ? h->d_cdf : nullptr;
+    d.ncdf = ncdf;
+    d.nspec = h->nspec;
+    d.spec_step = h->spec ? 1 : 0;
+    d.part_stride = pstride;
+    d.gx_launch = h->gx_launch;
     if (ok) {
         double *f = h->d_f64;
         d.z = f, f += nc * K;
         d.v = f, f += nc * K;
-        d.pz = f, f += nc * K;
-        d.pv = f, f += nc * K;
+        d.pz = f, f += nr * K;
+        d.pv = f, f += nr * K;
         d.sd = f, f += nc;
         d.logL = f, f += nc;
         d.ss = f, f += nc;
         d.beta = f, f += nc;
-        d.plp = f, f += nc;
-        d.V = f, f += nc * ldm;
-        d.D = f, f += nc * ldm;
+        d.plp = f, f += nr;
+        d.V = f, f += nr * ldm;
+        d.D = f, f += nr * ldm;
         int *i = h->d_i32;
         d.k = i, i += nc;
-        d.pk = i, i += nc;
-        d.pactive = i, i += nc;
+        d.pk = i, i += nr;
+        d.pactive = i, i += nr;
         d.NL = (int32_t *)i;
         d.ctr = h->d_u64;
         d.stats = (long long *)(h->d_u64 + nc);
@@ -528,24 +691,39 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.inc = h->d_inc;
         d.cache_valid = h->d_cache_valid;
         d.incremental = (h->incremental && h->d_partial_x) ? 1 : 0;  // (exact sums: the fused kernel path)
-        {
-            // the deepest source (once, on the host): proposals that change the model only below it need no launch
-            std::vector<double> dep(n);
-            ok = ok && hipStreamSynchronize(h->stream) == hipSuccess &&
-                 hipMemcpy(dep.data(), h->d_set + n, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-            double zm = -INFINITY;
-            for (double z : dep)
-                if (z == z && z > zm)
-                    zm = z;
-            d.zmax_src = zm;
+        int *q = h->d_spec_i32;
+        d.cur = q, q += nc;
+        d.fin = q, q += nc;
+        d.nwin = q, q += nc;
+        d.wend = q, q += nc;
+        d.winv = q, q += nc;
+        d.nact = q, q += nc;
+        d.wbuf = q, q += nc;
+        d.pend_i = q, q += 4 * nc;
+        d.pslot = q, q += nr;
+        d.pinv = q, q += nr;
+        d.rowwg = q, q += nr;
+        d.alist = q, q += nr;
+        d.wctr = h->d_spec_u64;
+        d.pctr = h->d_spec_u64 + nc;
+        d.pend_z = h->d_pend_z;
+        // one-at-a-time step: a chain's rows of the residual slab never change (current residuals: row c; its proposal's: row
+        // nchains + c); the speculative step writes them with every proposal
+        h->inc0.assign(nc, rtmi::PtInc{});
+        for (size_t q2 = 0; q2 < nc; ++q2) {
+            h->inc0[q2].mover = 1;
+            h->inc0[q2].cur_row = (int)q2;
+            h->inc0[q2].pend_row = h->inc0[q2].prop_row = (int)(nc + q2);
         }
+        if (!h->spec)
+            ok = hipMemcpyAsync(h->d_inc, h->inc0.data(), nc * sizeof(rtmi::PtInc), hipMemcpyHostToDevice, h->stream) == hipSuccess;
         // every chain starts as a half-space at the middle of the velocity prior, sigma 0.01, beta 1 (as the host
         // engine of round 1 did); rtmi_pt_set_chain overrides
         std::vector<double> init(nc * K, 0.0), sd0(nc, 0.01), b0(nc, 1.0);
         std::vector<int> k0(nc, 1);
-        for (size_t q = 0; q < nc; ++q)
-            init[q * K] = 0.5 * (prior->vmin + prior->vmax);
-        ok = hipMemcpyAsync(d.v, init.data(), nc * K * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+        for (size_t q2 = 0; q2 < nc; ++q2)
+            init[q2 * K] = 0.5 * (prior->vmin + prior->vmax);
+        ok = ok && hipMemcpyAsync(d.v, init.data(), nc * K * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipMemcpyAsync(d.sd, sd0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipMemcpyAsync(d.beta, b0.data(), nc * sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
              hipMemcpyAsync(d.k, k0.data(), nc * sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
@@ -572,7 +750,8 @@ void rtmi_pt_destroy(rtmi_pt *h)
     for (auto &g : h->graphs)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
-                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x};
+                    h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x,
+                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -595,7 +774,17 @@ int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const 
     HIP_TRY(hipMemcpyAsync(h->d.k + c, &k, sizeof(int), hipMemcpyHostToDevice, h->stream));
     // the residual cache belongs to the model that was here: invalid until a model of this chain has been evaluated in full
     HIP_TRY(hipMemsetAsync(h->d_cache_valid + c, 0, sizeof(int), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_inc + c, 0, sizeof(rtmi::PtInc), h->stream));
+    if (h->spec) {
+        // no window awaits a decision, no accepted proposal's residuals are pending
+        HIP_TRY(hipMemsetAsync(h->d_inc + c * (size_t)h->nspec, 0, (size_t)h->nspec * sizeof(rtmi::PtInc), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d.nwin + c, 0xFF, sizeof(int), h->stream));  // -1
+        HIP_TRY(hipMemsetAsync(h->d.nact + c, 0, sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d.cur + c, 0, sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d.fin + c, 0, sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d.pend_i + 4 * c, 0, 4 * sizeof(int), h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->d_inc + c, &h->inc0[c], sizeof(rtmi::PtInc), hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (k > h->kbound)
         h->kbound = k;
@@ -678,7 +867,10 @@ int rtmi_pt_evaluate(rtmi_pt *h)
     int rc = launch_likelihood(h);
     if (rc)
         return rc;
-    launch_step(h, PT_EVAL, 0, PT_NONE, 0, 0);
+    if (h->spec)
+        launch_step_spec(h, 0, 1);
+    else
+        launch_step(h, PT_EVAL, 0, PT_NONE, 0, 0);
     HIP_TRY(hipGetLastError());
     h->launches += 1;
     h->models += h->nchains;
@@ -978,7 +1170,7 @@ int rtmi_pt_likelihood_counts(const rtmi_pt *hc, int64_t *traced, int64_t *cache
     *traced = *cached = 0;
     if (!h->d_inc_counts)  // the incremental likelihood is off for this handle
         return RTMI_OK;
-    std::vector<unsigned long long> c((size_t)2 * h->nchains * h->d.gx);  // one pair per workgroup
+    std::vector<unsigned long long> c((size_t)2 * h->nrows * h->d.part_stride);  // one pair per workgroup
     HIP_TRY(hipMemcpy(c.data(), h->d_inc_counts, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long tr = 0, ca = 0;
     for (size_t i = 0; i + 1 < c.size(); i += 2) {
@@ -987,6 +1179,36 @@ int rtmi_pt_likelihood_counts(const rtmi_pt *hc, int64_t *traced, int64_t *cache
     }
     *traced = (int64_t)tr;
     *cached = (int64_t)ca;
+    return RTMI_OK;
+}
+
+int rtmi_pt_stream_positions(rtmi_pt *h, uint64_t *ctr)
+{
+    if (!h || !ctr)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_stream_positions: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(ctr, h->d.ctr, (size_t)h->nchains * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+int rtmi_pt_speculation(rtmi_pt *h, int64_t *out4)
+{
+    if (!h || !out4)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_speculation: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<long long> st((size_t)h->nchains * 8);
+    HIP_TRY(hipMemcpy(st.data(), h->d.stats, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long discarded = 0;
+    for (int c = 0; c < h->nchains; ++c)
+        discarded += st[(size_t)c * 8 + 7];
+    out4[0] = h->spec ? h->nspec : 1;
+    out4[1] = discarded;
+    out4[2] = h->engine;
+    out4[3] = h->d_partial_x ? 1 : 0;
     return RTMI_OK;
 }
 

@@ -38,12 +38,52 @@ struct PtDev {
     const double *partial;  // [nchains][gx] (the plain kernel's sums: small source sets)
     const unsigned long long *partial_x;  // [nchains][gx][4] or NULL: exact sums of the fused kernel's sampler form (Acc192)
     long long *stats;     // [nchains][8]: acc/prop birth-death, acc/prop perturbation, acc/prop sigma, models evaluated, -
-    // incremental likelihood (rtmi_kernels.h::PtInc): what the step tells the likelihood about each chain's proposal
-    rtmi::PtInc *inc;     // [nchains]
+    // incremental likelihood (rtmi_kernels.h::PtInc): what the step tells the likelihood about each model row's proposal
+    rtmi::PtInc *inc;     // [nchains * nspec]
     int *cache_valid;     // [nchains] r2cur holds the residuals of the chain's current model (cleared by rtmi_pt_set_chain)
     double zmax_src;      // the deepest source of the handle's set
     int incremental;      // the incremental likelihood is on (RTMI_PT_INCREMENTAL)
+    // the handle's sources are sorted by depth; a histogram of their depths bounds, with one load, the prefix of the set
+    // that lies above a given depth: sources [0, cdf[bin(z)]) have depths < z (PtInc::n0, pn0)
+    const int *cdf;       // [ncdf + 1] cdf[g] = sources whose bin is < g
+    int ncdf;
+    double cdf_z0, cdf_inv;  // bin(z) = clamp(floor((z - cdf_z0) * cdf_inv), 0, ncdf - 1)
+    int64_t nsrc;
+    // ---- speculative proposals (pt_step_spec below): nspec model rows per chain --------------------------------------
+    // Rows m = chain * nspec + e, e < nspec: pk, pactive, plp, pz, pv, V, D, NL, inc and the residual sums are indexed by ROW
+    // (nspec = 1: by chain, the non-speculative step).
+    int nspec;
+    int spec_step;        // the handle runs pt_step_spec (RTMI_PT_SPECULATE >= 1); 0 = the one-at-a-time step pt_step_group
+    int part_stride;      // residual sums of row m: partial_x[(m * part_stride + j) * 4], j < rowwg[m]
+    int *cur;             // [nchains] the chain's next undecided slot of the current sweep (0 = birth/death, s = (node s>>1, parameter s&1))
+    int *fin;             // [nchains] the sweep's sigma move is done: nothing left to do until the next sweep
+    int *nwin;            // [nchains] proposals of the window that await their decisions (entries e < nwin); -1 = no window
+    int *wend;            // [nchains] the slot after the window (where the chain goes on when every entry is rejected)
+    unsigned long long *wctr;  // [nchains] ... and the position of its random stream there
+    int *winv;            // [nchains] proposals outside the prior after the window's last entry: birth/death | perturbations << 8
+    int *pslot;           // [rows] the slot of entry e
+    int *pinv;            // [rows] proposals outside the prior between the entry before and this one (same packing)
+    unsigned long long *pctr;  // [rows] position of the random stream after the entry's proposal was drawn (= its acceptance draw)
+    int *rowwg;           // [rows] workgroups that evaluate the row (= partial sums to add up)
+    int *nact;            // [nchains] entries that go through the likelihood in this pass ...
+    int *alist;           // [rows]   ... and which (alist[chain * nspec + a] = e of the a-th)
+    int *wbuf;            // [nchains] which of the two sets of proposal rows (of the residual slab) the chain's rows write next
+    // chain-level record of the pending accepted proposal (copied into every row's PtInc)
+    double *pend_z;       // [nchains][3] pzthr, pdl1, pdl2
+    int *pend_i;          // [nchains][4] pending, pend_row, pn0, -
+    int gx_launch;        // per-slot engine: workgroups per row of the batched launch (rowwg of every evaluated row)
 };
+
+// Sources [0, prefix_above(d, z)) of the handle's depth-sorted set have depths < z: one load from the depth histogram (a
+// multiple of 64, conservative; 0 when z is not above the shallowest bin, or NaN).  bin() is the host's formula (rtmi_pt.hip).
+__device__ __forceinline__ int prefix_above(const PtDev &d, double z)
+{
+    if (!d.cdf || !(z > d.cdf_z0))
+        return 0;
+    const double t = (z - d.cdf_z0) * d.cdf_inv;
+    const int g = t >= (double)(d.ncdf - 1) ? d.ncdf - 1 : (int)t;
+    return d.cdf[g] & ~63;
+}
 
 #define PT_STEP_THREADS 256
 
@@ -152,6 +192,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 o->pzthr = ic.zthr;
                 o->pdl1 = ic.dl1;
                 o->pdl2 = ic.dl2;
+                o->pn0 = ic.n0;
                 if (ic.zthr == -INFINITY && !cache_ok)
                     d.cache_valid[c] = 1;
             }
@@ -350,6 +391,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 o->zthr = zthr;
                 o->dl1 = dl_cur;
                 o->dl2 = dl_new;
+                o->n0 = prefix_above(d, fmin(zthr, fmin(dl_cur, dl_new)));  // (the rows of the residual slab never change here)
             }
         }
         if (trivial)
@@ -360,6 +402,458 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     if (lead) {
         d.NL[c] = nl;
         d.ctr[c] = rng.index;
+    }
+}
+
+
+// =====================================================================================================================
+// The SPECULATIVE step (exact: chains advance bit for bit as with pt_step_group).
+//
+// A perturbation is accepted about one time in five, so four times in five the state after a proposal slot is the state
+// before it; and the chain's random stream is counter-based, so the proposals of the slots s, s + 1, ... ASSUMING EVERY ONE
+// OF THEM IS REJECTED are all known at once -- each is drawn from the same model, at a stream position that is fixed by the
+// draws of the ones before it.  One step therefore proposes a WINDOW of up to `nspec` models (one model row each,
+// m = chain * nspec + e), one likelihood pass evaluates them side by side, and the next step walks their decisions IN ORDER
+// with the very acceptance draws the one-at-a-time sampler would take: the first accepted entry becomes the state, the
+// entries behind it are discarded (they were drawn from a state that no longer is the chain's) and the chain goes on from
+// the slot after it; if none is accepted the whole window is retired.  Same draws, same sums (they are exact integers), same
+// decisions: prjmh_temper_rf.f90:721-759 (sequential perturbations), :669-713 (birth / death), :561-569 (sigma) are run
+// as written, only the likelihoods are evaluated ahead of time.
+//
+// Per chain: `cur` = its next undecided slot (0 = birth/death, s = (node s >> 1, parameter s & 1); a chain with k nodes has
+// the slots 0 .. 2k - 1, then the sigma move; slots of nodes it does not have do not exist for it), `fin` = the sweep is
+// complete.  Proposals outside the prior cost no model row and no acceptance draw; they are counted when the entries around
+// them are decided (pinv / winv), so that the statistics are those of the one-at-a-time sampler as well.
+// Incremental likelihood: the rows of a window all read the chain's current residuals (r2cur, or the pending accepted
+// proposal's row) and write rows of their own; the two sets of proposal rows alternate whenever a proposal is accepted, so no
+// row is read and written in the same pass, and exactly one row of a pass (the first that is evaluated) moves the pending
+// residuals to r2cur.
+// begin: first step of a sweep.  eval: decide an evaluation of the current state (rtmi_pt_evaluate) and propose nothing.
+// wg_total: workgroups the chain's rows share in the next pass (persistent engine; they are dealt to the evaluated rows
+// round-robin), 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows).
+#define PT_SPEC_MAX 4  // (the window's records are held in registers; the step shares the sweep kernel's 128)
+
+template <int G>
+__device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const int begin, const int eval, const int wg_total)
+{
+    namespace R = rtmi_pt_rules;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
+    const int i = lane - gbase;               // the node this lane holds
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gbase;
+    const int K = d.K, D = d.nspec;
+    const rtmi_pt_prior &p = d.pr;
+    const bool lead = i == 0;
+    const int ic_ = i < K ? i : 0;
+    const size_t row = (size_t)c * K + ic_;
+    const int m0 = c * D;                     // the chain's first model row
+    // ---- one round trip to HBM: the chain, its window, the Poisson table -----------------------------------------------
+    double zi = d.z[row], vi = d.v[row];
+    const double lpk_lo = d.logpk[i < K + 2 ? i : K + 1], lpk_hi = d.logpk[i + G < K + 2 ? i + G : K + 1];
+    int k = d.k[c];
+    unsigned long long ctr = d.ctr[c];
+    double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
+    const double beta = d.beta[c];
+    int cache_ok = d.cache_valid[c];
+    int cur = begin ? 0 : d.cur[c];
+    int fin = begin ? 0 : d.fin[c];
+    const int nwin = begin ? -1 : d.nwin[c];  // -1: no window awaits its decisions; 0: one without entries (its draws and its proposals outside the prior still count)
+    const int wend = d.wend[c], winv = d.winv[c];
+    const unsigned long long wctr = d.wctr[c];
+    int wbuf = d.wbuf[c];
+    int pending = d.pend_i[4 * c + 0], pend_row = d.pend_i[4 * c + 1], pn0 = d.pend_i[4 * c + 2];
+    double pzthr = d.pend_z[3 * c + 0], pdl1 = d.pend_z[3 * c + 1], pdl2 = d.pend_z[3 * c + 2];
+    int e_act[PT_SPEC_MAX], e_pk[PT_SPEC_MAX], e_slot[PT_SPEC_MAX], e_inv[PT_SPEC_MAX], e_wg[PT_SPEC_MAX];
+    unsigned long long e_ctr[PT_SPEC_MAX];
+    double e_lp[PT_SPEC_MAX];
+#pragma unroll
+    for (int e = 0; e < PT_SPEC_MAX; ++e) {
+        const bool on = e < D && e < nwin;
+        const int m = m0 + (on ? e : 0);
+        e_act[e] = on ? d.pactive[m] : 0;
+        e_pk[e] = on ? d.pk[m] : 0;
+        e_slot[e] = on ? d.pslot[m] : 0;
+        e_inv[e] = on ? d.pinv[m] : 0;
+        e_wg[e] = on ? d.rowwg[m] : 0;
+        e_ctr[e] = on ? d.pctr[m] : 0ull;
+        e_lp[e] = on ? d.plp[m] : 0.0;
+    }
+    // SUM(DresRT**2) of every evaluated entry: its workgroups' exact sums (any order gives the same words)
+    double e_part[PT_SPEC_MAX];
+#pragma unroll
+    for (int e = 0; e < PT_SPEC_MAX; ++e) {
+        e_part[e] = 0.0;
+        if (e < D && (e_act[e] == 1 || e_act[e] == 2)) {
+            rtmi::Acc192 tot = rtmi::acc_zero();
+            for (int j = 0; j < e_wg[e]; ++j) {
+                const unsigned long long *w = d.partial_x + 4 * ((size_t)(m0 + e) * d.part_stride + j);
+                rtmi::Acc192 o;
+                o.w0 = w[0];
+                o.w1 = w[1];
+                rtmi::acc_add(tot, o);
+            }
+            e_part[e] = rtmi::acc_to_double(tot);
+        }
+    }
+    long long *st = d.stats + (size_t)c * 8;
+    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr);
+
+    // ---- decisions of the window, in order (prjmh_temper_rf.f90:697-706, :742-751) -------------------------------------
+    bool taken = false, had_eval = false;
+    int e_acc = -1, n_after = 0;
+    long long d_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < PT_SPEC_MAX; ++e) {
+        if (e < D && e < nwin) {
+            const int act = e_act[e];
+            had_eval = had_eval || act == 1 || act == 2;
+            if (taken) {
+                n_after += act == 1 ? 1 : 0;  // evaluated for nothing: drawn from a state that is not the chain's any more
+            } else {
+                d_st[1] += e_inv[e] & 0xFF;   // proposed, rejected outside the prior (:707-711)
+                d_st[3] += e_inv[e] >> 8;
+                const double part = act == 3 ? ss : e_part[e];  // (3: no source is affected -- the sum IS the current one)
+                // a NaN likelihood (NaN data, an unusable model row) is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
+                double logl_new = R::gaussian_loglike(part, d.ndata, sd);
+                if (logl_new != logl_new)
+                    logl_new = -1.7976931348623157e308;
+                if (act == 2) {
+                    ss = part;
+                    logL = logl_new;
+                    taken = true;
+                    e_acc = e;
+                } else {
+                    const int kind = e_slot[e] == 0 ? (int)PT_BD : (int)PT_MH;
+                    double lr = e_lp[e] + (logl_new - logL) * beta;
+                    if (lr > 50.0)
+                        lr = 50.0;
+                    d_st[2 * kind + 1] += 1;
+                    d_st[6] += 1;  // a model that went through the likelihood and was decided
+                    rng.index = e_ctr[e];
+                    const double u_acc = R::philox_uniform(rng);
+                    ctr = rng.index;
+                    cur = e_slot[e] + 1;
+                    // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects
+                    if (lr == lr && !(u_acc >= exp(lr))) {
+                        k = e_pk[e];
+                        ss = part;
+                        logL = logl_new;
+                        d_st[2 * kind] += 1;
+                        taken = true;
+                        e_acc = e;
+                    }
+                }
+            }
+        }
+    }
+    if (nwin >= 0) {
+        if (!taken) {  // the whole window is retired
+            cur = wend;
+            ctr = wctr;
+            d_st[1] += winv & 0xFF;
+            d_st[3] += winv >> 8;
+        }
+        d_st[7] += n_after;
+        // The pass that evaluated this window has moved the residuals of an earlier accepted proposal to r2cur (its mover
+        // row).  If an evaluated entry is taken, ITS residuals (in its row, for the sources it affected) are the pending ones
+        // now, and the chain's next rows write the other set; a model evaluated in full makes the cache valid.
+        if (had_eval)
+            pending = 0;
+        if (taken) {
+            int a_act = 0;
+#pragma unroll
+            for (int e = 0; e < PT_SPEC_MAX; ++e)
+                if (e == e_acc)
+                    a_act = e_act[e];
+            const int m = m0 + e_acc;
+            if (a_act != 2) {  // the proposal becomes the state (one more round trip, for the entry that was taken only)
+                if (i < k) {
+                    zi = d.pz[(size_t)m * K + ic_];
+                    vi = d.pv[(size_t)m * K + ic_];
+                    d.z[row] = zi;
+                    d.v[row] = vi;
+                }
+                if (lead)
+                    d.k[c] = k;
+            }
+            if (a_act != 3) {
+                const rtmi::PtInc *o = d.inc + m;
+                pending = 1;
+                pzthr = o->zthr;
+                pdl1 = o->dl1;
+                pdl2 = o->dl2;
+                pn0 = o->n0;
+                pend_row = o->prop_row;
+                wbuf ^= 1;
+                if (pzthr == -INFINITY && !cache_ok) {
+                    cache_ok = 1;
+                    if (lead)
+                        d.cache_valid[c] = 1;
+                }
+            }
+        }
+    }
+
+    // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630) once every slot of the sweep is decided ------------------
+    if (!eval && !fin && cur >= 2 * k) {
+        rng.index = ctr;
+        if (R::philox_uniform(rng) >= 0.10) {
+            const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
+            const double sd_new = sd + step * R::philox_normal(rng);
+            d_st[5] += 1;
+            if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
+                double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
+                if (logl_new != logl_new)
+                    logl_new = -1.7976931348623157e308;  // as above
+                double lr = (logl_new - logL) * beta;
+                if (lr > 50.0)
+                    lr = 50.0;
+                const double u_acc = R::philox_uniform(rng);
+                if (lr == lr && !(u_acc >= exp(lr))) {
+                    sd = sd_new;
+                    logL = logl_new;
+                    d_st[4] += 1;
+                }
+            }
+        }
+        ctr = rng.index;
+        fin = 1;
+    }
+    if (lead) {
+        d.sd[c] = sd;
+        d.logL[c] = logL;
+        d.ss[c] = ss;
+        d.ctr[c] = ctr;
+        d.cur[c] = cur;
+        d.fin[c] = fin;
+        d.wbuf[c] = wbuf;
+        d.pend_i[4 * c + 0] = pending;
+        d.pend_i[4 * c + 1] = pend_row;
+        d.pend_i[4 * c + 2] = pn0;
+        d.pend_z[3 * c + 0] = pzthr;
+        d.pend_z[3 * c + 1] = pdl1;
+        d.pend_z[3 * c + 2] = pdl2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (d_st[j])
+                st[j] += d_st[j];
+    }
+
+    // ---- the next window: proposals of the slots cur, cur + 1, ... all drawn from the chain's state ----------------------
+    // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the chain-dependent branches.
+    const double zi0 = zi, vi0 = vi;
+    const int up = lane + 1 < 64 ? lane + 1 : 63;
+    const double z_up = __shfl(zi0, up, 64), v_up = __shfl(vi0, up, 64);  // node i + 1 (death shifts the nodes down)
+    const int kc = k < 1 ? 1 : k;
+    const double lpk_k = kc < G ? __shfl(lpk_lo, gbase + (kc & (G - 1)), 64) : __shfl(lpk_hi, gbase + ((kc - G) & (G - 1)), 64);
+    const double lpk_kp = kc + 1 < G ? __shfl(lpk_lo, gbase + ((kc + 1) & (G - 1)), 64)
+                                     : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
+    const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
+                                     : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
+    auto group_max = [&](double x) {
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1)
+            x = fmax(x, __shfl_xor(x, off, 64));
+        return x;
+    };
+    const double dl_cur = k == 1 ? 9999.9 : group_max((i >= 1 && i < k) ? zi0 : -INFINITY);
+    const double zmin_cur = -group_max(i < k ? -zi0 : -INFINITY);  // the shallowest node: its velocity is the TOP layer's
+    int e = 0, s = cur, nact = 0;
+    int inv = 0;                 // proposals outside the prior since the last entry
+    int my_e = -1;               // lane a: the a-th evaluated entry of the window ...
+    double my_zeff = -INFINITY;  // ... and the depth above which no source is affected by it
+    unsigned long long idx = ctr;
+    bool going = !eval && !fin && s < 2 * k;
+    while (__any(going)) {
+        const int propose = s == 0 ? (int)PT_BD : (int)PT_MH;
+        const int ivo = s >> 1, ipar = s & 1;
+        rng.index = idx;
+        zi = zi0;
+        vi = vi0;
+        int moved_node = 0;     // death: the removed node; perturbation: the node; birth: the new node
+        double zthr = -INFINITY;
+        int qk = k;
+        double lp = 0.0;
+        bool have = false;
+        if (going) {
+            if (propose == PT_BD) {
+                // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
+                if (p.kmin != p.kmax) {
+                    const double u = R::philox_uniform(rng);
+                    int move;
+                    if (k == p.kmax)
+                        move = (u <= 0.3333) ? 2 : 0;
+                    else if (k == p.kmin)
+                        move = (u <= 0.3333) ? 1 : 0;
+                    else
+                        move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
+                    if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
+                        const double zn = (p.hmx - p.hmin) * R::philox_uniform(rng);
+                        const double vn = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
+                        if (i == k) {
+                            zi = zn;
+                            vi = vn;
+                        }
+                        qk = k + 1;
+                        lp = lpk_kp - lpk_k;
+                        have = true;
+                        moved_node = k;
+                        zthr = zn;
+                    } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
+                        int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
+                        if (idel > k - 1)
+                            idel = k - 1;
+                        if (i >= idel && i + 1 < k) {
+                            zi = z_up;
+                            vi = v_up;
+                        }
+                        qk = k - 1;
+                        lp = lpk_km - lpk_k;
+                        have = true;
+                        moved_node = idel;
+                        zthr = INFINITY;  // = the removed node's depth: taken from its lane below
+                    }
+                }
+            } else {
+                // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
+                const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
+                const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
+                if (i == ivo) {
+                    if (ipar == 0)
+                        zi += step;
+                    else
+                        vi += step;
+                }
+                have = true;
+                moved_node = ivo;
+                zthr = INFINITY;      // = min(old, new depth) of the node (a velocity leaves the depth as it is): from its lane below
+            }
+        }
+        const double z_old_moved = __shfl(zi0, gbase + (moved_node & (G - 1)), 64);
+        {
+            const double z_new = __shfl(zi, gbase + (moved_node & (G - 1)), 64);
+            if (zthr == INFINITY)
+                zthr = (propose == PT_BD) ? z_old_moved : fmin(z_old_moved, z_new);
+            if (!cache_ok || !(zthr == zthr))
+                zthr = -INFINITY;  // no valid cache yet (or a NaN depth): evaluate in full
+        }
+        // CHECKBOUNDS (prjmh_temper_rf.f90:1639-1679; rtmi_pt_rules.h::inside_bounds) over the qk proposed nodes
+        const bool in = have && i < qk;
+        bool bad = in && (vi < p.vmin || vi > p.vmax);
+        bad = bad || (in && qk > 1 && i >= 1 && (zi < 0.0 || zi > p.hmx));
+        int r = 0;  // rank of this node in depth (stable)
+        for (int j = 0; j < K; ++j) {
+            const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
+            r += (in && j < qk && (zj < zi || (zj == zi && j < i))) ? 1 : 0;
+        }
+        double prev = 0.0;  // the node above in depth; the rule measures the second node's spacing from 0
+        for (int j = 0; j < K; ++j) {
+            const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
+            const int rj = __shfl(r, gbase + (j & (G - 1)), 64);
+            if (j < qk && r >= 2 && rj == r - 1)
+                prev = zj;
+        }
+        bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
+        // (see pt_step_group: a move that involves the shallowest node changes the model from the surface downwards)
+        {
+            const int r_moved = __shfl(r, gbase + (moved_node & (G - 1)), 64);
+            const bool removed = propose == PT_BD && qk < k;
+            const bool touches_top = have && ((moved_node < k && z_old_moved <= zmin_cur) || (!removed && r_moved == 0));
+            if (touches_top)
+                zthr = -INFINITY;
+        }
+        const double dl_all = group_max((in && i >= 1) ? zi : -INFINITY);
+        const double dl_new = qk == 1 ? 9999.9 : dl_all;
+        const bool ok = have && (__ballot(bad) & gmask) == 0ull;
+        const bool trivial = d.incremental && cache_ok && zthr > d.zmax_src && dl_cur > d.zmax_src && dl_new > d.zmax_src;
+        if (going) {
+            if (ok) {
+                // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision: row m0 + e
+                const int m = m0 + e;
+                double *Vr = d.V + (size_t)m * d.ld_model, *Dr = d.D + (size_t)m * d.ld_model;
+                int nl;
+                if (qk == 1) {
+                    if (lead) {
+                        Vr[0] = Vr[1] = vi;
+                        Dr[0] = 9999.9;
+                    }
+                    nl = 1;
+                } else {
+                    if (in) {
+                        Vr[r] = vi;
+                        if (r >= 1)
+                            Dr[r - 1] = zi;
+                    }
+                    nl = qk - 1;
+                }
+                if (in && i < K) {
+                    d.pz[(size_t)m * K + i] = zi;
+                    d.pv[(size_t)m * K + i] = vi;
+                }
+                if (!trivial && i == nact) {
+                    my_e = e;
+                    my_zeff = fmin(zthr, fmin(dl_cur, dl_new));
+                }
+                if (lead) {
+                    d.pk[m] = qk;
+                    d.plp[m] = lp;
+                    d.pactive[m] = trivial ? 3 : 1;
+                    d.pslot[m] = s;
+                    d.pinv[m] = inv;
+                    d.pctr[m] = rng.index;
+                    d.NL[m] = trivial ? 0 : nl;  // (trivial: an inactive row -- nothing to evaluate)
+                    if (!trivial) {
+                        rtmi::PtInc *o = d.inc + m;
+                        o->zthr = zthr;
+                        o->dl1 = dl_cur;
+                        o->dl2 = dl_new;
+                        o->pzthr = pzthr;
+                        o->pdl1 = pdl1;
+                        o->pdl2 = pdl2;
+                        o->pending = pending;
+                        o->pn0 = pn0;
+                        o->mover = nact == 0 ? 1 : 0;
+                        o->cur_row = c;
+                        o->pend_row = pend_row;
+                        o->prop_row = d.nchains + (wbuf * d.nchains + c) * D + e;
+                        d.alist[m0 + nact] = e;
+                    }
+                }
+                nact += trivial ? 0 : 1;
+                inv = 0;
+                idx = rng.index + 1;  // (the acceptance draw)
+                ++e;
+            } else {
+                if (have)
+                    inv += propose == PT_BD ? 1 : 256;
+                idx = rng.index;
+            }
+            ++s;
+            going = e < D && s < 2 * k;
+        }
+    }
+    // rows beyond the window are inactive; every evaluated row learns how many workgroups it gets and which prefix of the
+    // sorted sources lies above everything its proposal changes
+    if (i < D) {
+        const int m = m0 + i;
+        if (i >= e)
+            d.NL[m] = 0;
+        if (eval)
+            ;  // (the rows of an evaluation were written by pt_pack_current_kernel)
+        else if (i < nact) {
+            d.rowwg[m0 + my_e] = wg_total > 0 ? (wg_total - i + nact - 1) / nact : d.gx_launch;
+            d.inc[m0 + my_e].n0 = prefix_above(d, my_zeff);
+        }
+    }
+    if (lead && !eval) {
+        d.nwin[c] = fin ? -1 : e;
+        d.wend[c] = s;
+        d.wctr[c] = idx;
+        d.winv[c] = inv;
+        d.nact[c] = nact;
+    }
+    if (lead && eval) {
+        d.nwin[c] = -1;
+        d.nact[c] = 0;
     }
 }
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "rtmi_pt_sweep": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rtmi_pt_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_likelihood_counts": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_stream_positions": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "rtmi_pt_speculation": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_set_ladder": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]),
     "rtmi_pt_get_ladder": (ctypes.c_int, [_vp, _ip, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_swap_round": (ctypes.c_int, [_vp, _vp]),
@@ -398,6 +400,19 @@ class NativeChains:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         _check(self.lib.rtmi_pt_likelihood_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
+
+    def stream_positions(self):
+        """Draws every chain's counter-based random stream has taken so far (part of the chain's state)."""
+        out = (ctypes.c_uint64 * self.n)()
+        _check(self.lib.rtmi_pt_stream_positions(self.h, out))
+        return np.array(out[:], dtype=np.uint64)
+
+    def speculation(self):
+        """{rows: model rows per chain of the speculative step (1 = off), discarded: models evaluated for nothing,
+        engine: -1 undecided / 0 per-slot launches / 1 persistent launch, sorted_sources}."""
+        out = (ctypes.c_int64 * 4)()
+        _check(self.lib.rtmi_pt_speculation(self.h, out))
+        return {"rows": int(out[0]), "discarded": int(out[1]), "engine": int(out[2]), "sorted_sources": bool(out[3])}
 
     def stats(self):
         out = (ctypes.c_int64 * 8)()

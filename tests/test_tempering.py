@@ -676,3 +676,93 @@ def test_device_sampler_maps_a_nan_likelihood_to_minus_huge():
     a = h.get_all()
     assert np.all(a["logL"] == -sys.float_info.max), a["logL"]
     assert rt.load_library().rtmi_device_status() == 0
+
+
+def _run_native(shape, env):
+    """One run of the device sampler on a fixed problem under the given environment; returns everything that is a chain's
+    state or a statistic (launch counters excluded)."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h = raymod.NativeChains(shape["nch"], shape["ld"], shape["off"].size, shape["prior"], seed=shape["seed"])
+        for i in range(shape["nch"]):
+            h.set_chain(i, shape["nodes"][i % len(shape["nodes"])], shape["sd"], 1.0)
+        h.evaluate()
+        nlev = shape["nch"] // 2
+        h.set_ladder(shape["nch"], 0, np.arange(shape["nch"]) // 2, 1.15 ** -np.arange(float(nlev)))
+        h.sample_buffer(4096)
+        h.run(shape["sweeps"], 1, None, 3)
+        a = h.get_all()
+        live = np.arange(a["z"].shape[1])[None, :] < a["k"][:, None]
+        st = {k: v for k, v in h.stats().items() if k != "launches"}
+        smp = h.samples()
+        order = np.lexsort((smp["chain"], smp["sweep"]))
+        out = {"k": a["k"], "z": np.where(live, a["z"], 0.0), "v": np.where(live, a["v"], 0.0), "sd": a["sd"], "logL": a["logL"],
+               "ss": a["ss"], "beta": a["beta"], "ctr": h.stream_positions(), "level": h.get_ladder()[0],
+               "smp_k": smp["k"][order], "smp_logL": smp["logL"][order], "smp_sd": smp["sd"][order]}
+        info = h.speculation()
+        del h
+        assert rt.load_library().rtmi_device_status() == 0
+        return out, st, info
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_speculative_step_is_exact(kat):
+    """The speculative step (csrc/rtmi_pt_dev.hpp::pt_step_spec: the next proposals ASSUMING REJECTION are evaluated side by
+    side in one likelihood pass and decided in order; prjmh_temper_rf.f90:721-759, :669-713, :561-569 run as written, only
+    the likelihoods are evaluated ahead of time) must leave every chain -- k, nodes, sigma, logL, SS, temperature, the
+    POSITION OF ITS RANDOM STREAM -- every statistic, the ladder and the recorded samples bit-identical to the one-at-a-time
+    step (RTMI_PT_SPECULATE=0), with 1 ... 4 model rows per chain, in both engines.  Shapes: the reference's test_1 data (20
+    sources, fused kernel path forced: a source set smaller than one chunk), BASELINE config 4 in miniature (k up to 30,
+    birth / death active), and the config-3 shape with interfaces planted exactly on source depths."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import synthetic as S
+    from oracle import oracle as O
+    rt.load_library(); rt.init(0)
+    m = kat["model"]
+    shapes = []
+    off, dep, obs = (np.asarray(kat[k], float) for k in ("test_1_src_offset", "test_1_src_depth", "test_1_obs_RT"))
+    shapes.append({"name": "test_1", "off": off, "dep": dep, "obs": obs, "nch": 8, "ld": 11, "prior": T.Prior(), "seed": 5,
+                   "nodes": [np.column_stack([[0.0] + m["depths"], m["vels"]])], "sd": 0.02, "sweeps": 60, "force_fused": True})
+    off, dep = S.sampler_sources(3000, 77)
+    rng = np.random.default_rng(78)
+    z = np.concatenate([[0.0], np.sort(rng.uniform(300.0, 9000.0, 11))])
+    z[1:] += np.arange(11) * 150.0
+    nodes12 = np.column_stack([z, rng.uniform(2000.0, 8000.0, 12)])
+    vv, dd = T.layering(nodes12)
+    obs = O.oracle_dff(vv, dd, off, dep) + rng.normal(0.0, 0.02, off.size)
+    shapes.append({"name": "config-4 miniature", "off": off, "dep": dep, "obs": obs, "nch": 16, "ld": 31,
+                   "prior": T.Prior(kmin=2, kmax=30, lam=10.0), "seed": 9, "nodes": [nodes12], "sd": 0.02, "sweeps": 30})
+    n = 10_000
+    off, dep = S.sampler_sources(n, 6)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"] + np.random.default_rng(3).normal(0, 0.016, n)
+    base = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    n_last, n_in = base.copy(), base.copy()
+    n_last[-1, 0] = dep[int(np.argmin(np.where(dep > 3970.0, dep, np.inf)))]   # whichLayer's special case: dl1 / dl2 of the cache
+    n_in[3, 0] = dep[int(np.argmin(np.abs(dep - 2000.0)))]
+    shapes.append({"name": "config-3 shape", "off": off, "dep": dep, "obs": obs, "nch": 32, "ld": 11, "prior": T.Prior(),
+                   "seed": 21, "nodes": [base, n_last, n_in], "sd": 0.016, "sweeps": 25})
+    for sh in shapes:
+        rt.set_option("path", 2 if sh.get("force_fused") else 0)
+        try:
+            rt.set_sources(sh["off"], sh["dep"], sh["obs"])
+            ref, ref_st, info0 = _run_native(sh, {"RTMI_PT_SPECULATE": "0", "RTMI_PT_PERSISTENT": "0"})
+            assert info0["rows"] == 1 and ref_st["acc_mh"] > 0
+            for spec, pers in ((1, "0"), (2, "0"), (4, "0"), (3, "1"), (4, "1"), (0, "1")):
+                got, st, info = _run_native(sh, {"RTMI_PT_SPECULATE": str(spec), "RTMI_PT_PERSISTENT": pers})
+                assert info["rows"] == max(1, spec), (sh["name"], spec, info)
+                for key in ref:
+                    assert np.array_equal(ref[key], got[key]), (sh["name"], spec, pers, key)
+                assert st == ref_st, (sh["name"], spec, pers, st, ref_st)
+                if spec > 1:
+                    assert info["discarded"] > 0           # proposals behind an accepted one WERE evaluated and thrown away
+        finally:
+            rt.set_option("path", 0)
