@@ -95,9 +95,11 @@ def host_cores() -> int:
 
 
 def measured_counters(kernel_substr: str = "fused_kernel"):
-    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
-    (profiles/<tag>/pmc_summary.json, newest tag): (HBM bytes with FETCH_SIZE doubled per the gfx950 correction,
-    VALU wave-instructions, source file).  None if absent."""
+    """Per-launch PMC figures of the dominant kernel from the COMMITTED rocprofv3 passes of this same command
+    (profiles/<tag>/pmc_summary.json, newest tag) -- figures of another run on another box, possibly of an earlier build:
+    returned with the file's own record of the build it measured (`build_commit`, written by profiles/summarize.py).
+    (HBM bytes with FETCH_SIZE doubled per the gfx950 correction, VALU wave-instructions, source file, build commit).
+    None if absent."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json"))):
@@ -105,16 +107,75 @@ def measured_counters(kernel_substr: str = "fused_kernel"):
             d = json.load(open(path))
         except Exception:
             continue
+        commit = d.get("build_commit") if isinstance(d.get("build_commit"), str) else None
         for k, c in d.items():
-            if kernel_substr in k and "hbm_bytes_per_launch" in c:
+            if isinstance(c, dict) and kernel_substr in k and "hbm_bytes_per_launch" in c:
                 valu = c.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
-                best = (c["hbm_bytes_per_launch"]["total"], valu, os.path.relpath(path, ROOT))
+                best = (c["hbm_bytes_per_launch"]["total"], valu, os.path.relpath(path, ROOT), commit)
     return best
 
 
 def measured_traffic(kernel_substr: str = "fused_kernel"):
     m = measured_counters(kernel_substr)
-    return None if m is None else (m[0], m[2])
+    return None if m is None else (m[0], m[2], m[3])
+
+
+def c2_roofline(n: int, kern_ms: float, kernel_name: str):
+    """The `roofline` and `valu_fp64` objects of the C2 line.  Measured in this run: the kernel's average duration (HIP events on
+    the launch stream) and its name (from the library's own dispatch).  NOT measured in this run, and labelled so: HBM traffic and
+    VALU instruction counts, which come from the committed rocprofv3 --pmc passes of this same command (another box, possibly an
+    earlier build -- the file's `build_commit` is quoted)."""
+    achieved = BYTES_PER_TT * n / (kern_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
+            "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; see DESIGN.md section 4"}
+    tr = measured_traffic()
+    if tr is not None and n == 1_000_000:
+        roof["traffic"] = tr[0]
+        roof["traffic_source"] = ("NOT MEASURED IN THIS RUN: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command, %s, build %s" % (tr[1], tr[2] or "not recorded in that file"))
+    # the roof that actually binds: the fp64 vector ALU.  One wave-instruction occupies a SIMD for 4 cycles (v_rsq/v_rcp_f64:
+    # 16), i.e. 16 lanes per clock and SIMD = FP64_VALU_PEAK_TFLOPS / 2 lane-instructions per second over the chip.
+    peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
+    valu = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
+            "note": "fp64 VALU issue is the binding roof (DESIGN.md section 4.2)"}
+    mc = measured_counters()
+    if mc is not None and mc[1] and n == 1_000_000 and kern_ms:
+        valu["executed_valu_wave_instr_per_launch"] = mc[1]
+        valu["executed_frac_of_peak"] = mc[1] * 64.0 / (kern_ms * 1e-3) / peak_lane_instr
+        valu["source"] = "NOT MEASURED IN THIS RUN: %s, build %s (with this run's kernel time)" % (mc[2], mc[3] or "not recorded in that file")
+    return roof, valu
+
+
+def level_hash(level) -> int:
+    """CRC-32 of a temperature-level vector (int32, global chain order): equal on every rank iff the ranks took the same
+    swap decisions."""
+    import zlib
+    return int(zlib.crc32(np.ascontiguousarray(level, dtype=np.int32).tobytes()))
+
+
+def hashes_agree(h: int, dist, world: int, device="cpu") -> bool:
+    """All-reduce (MIN and MAX) of a rank's hash: True iff every rank holds the same value."""
+    if dist is None or world == 1:
+        return True
+    import torch
+    lo = torch.tensor([h], dtype=torch.int64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return int(lo[0]) == int(hi[0])
+
+
+def chain_parallel_block(level, rccl_ranks, world, elapsed_s, sweeps, models, nsrc, nloc, dist, red_device, rccl_info, engine, exchange):
+    """The `chain_parallel` object of the bench line (BASELINE configs 3/4: chains sharded over ranks, one logL all-gather
+    per swap round): what an N-GPU line must show for the north_star's chain-parallel scaling claim -- the communicator's size
+    as the LIBRARY reports it, the time per sweep (MAX over ranks), and proof that every rank ended with the same ladder."""
+    h = level_hash(level)
+    return {"rccl_ranks": int(rccl_ranks), "ranks": int(world), "chains": int(nloc * world), "chains_per_gpu": int(nloc),
+            "sources": int(nsrc), "sweeps": int(sweeps), "ms_per_sweep": elapsed_s / max(1, sweeps) * 1e3,
+            "models_per_s": models / elapsed_s, "travel_times_per_s": models * nsrc / elapsed_s,
+            "level_hash": h, "level_hash_equal_across_ranks": hashes_agree(h, dist, world, red_device),
+            "swap_every": 1, "exchange": exchange, "engine": engine, **rccl_info}
 
 
 def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
@@ -296,6 +357,7 @@ def bench_c4(args, rt, torch, dist, rank, world, dev):
     elapsed, kern_ms = timed_steps(step, args.steps, args.warmup, world, dist if world > 1 else None, dev,
                                    sync=torch.cuda.synchronize,
                                    make_event=lambda: torch.cuda.Event(enable_timing=True), stream=stream)
+    kernel_name = rt.last_kernel_name()
     if rank == 0:
         value = world * nm * nsrc * args.steps / elapsed
         algo = 16.0 * nm * nsrc + 8.0 * nm   # shared sources re-read per model, one logL per model
@@ -310,7 +372,7 @@ def bench_c4(args, rt, torch, dist, rank, world, dev):
                           "sharding": "chains (models) per rank, sources replicated, no collective in the step"},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                            "kernel": "rtmi::fused_kernel<double, false, false, true, false, false> + loglike_kernel",
+                            "kernel": kernel_name + " + rtmi::loglike_kernel",
                             "algorithmic_bytes_per_launch": algo,
                             "note": "fp64-VALU-bound root-find (DESIGN.md section 4)"},
                "logL_finite": bool(torch.isfinite(out["L"]).all().item())}
@@ -386,28 +448,38 @@ def bench_c5(args, rt, torch, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
-def bench_pt(args, rt, torch, dist, rank, world, dev):
-    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, device-resident sweep csrc/rtmi_pt.hip): 32 chains per GPU over 1e4 shared sources
-    (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
-    logL all-gather over RCCL.  A "step" is one sweep of every chain; value = travel times traced per second."""
-    from raytracerfortran_amd import tempering as T
-    nsrc = 10_000 if args.nsrc == 1_000_000 else args.nsrc
-    rng = np.random.default_rng(2024)
+def rccl_info(rt):
+    """Which RCCL the library's communicator binds to (a process holds torch's bundled copy too): version and the path of the
+    shared object that ncclAllGather resolves to INSIDE librtmi.so."""
+    try:
+        return {"rccl_version": rt.comm_rccl_version(), "rccl_library": rt.comm_rccl_library()}
+    except Exception as e:  # pragma: no cover
+        return {"rccl_version": None, "rccl_library": "unknown (%s)" % e}
+
+
+def pt_problem(torch, rt, dev, nsrc, seed=2024):
+    """Synthetic data of the sampler workloads: the reference's example geometry and 7-layer model + N(0, 0.016 s)."""
+    rng = np.random.default_rng(seed)
     x, y = rng.uniform(10, 6500, nsrc), rng.uniform(10, 4500, nsrc)
     off, dep = np.sqrt(x * x + y * y), rng.uniform(1050, 4200, nsrc)
-    v = [3100.0, 2400.0, 3730.0, 4200.0, 5800.0, 4420.0, 6200.0]
-    d = [1000.0, 1500.0, 2000.0, 2500.0, 3260.0, 3960.0]
-    # observations = forward(true model) + N(0, 0.016 s), generated with the HIP path itself (synthetic data)
     f64 = torch.float64
-    tt = rt.trace_device(torch.tensor(v, device=dev, dtype=f64), torch.tensor(d, device=dev, dtype=f64),
+    # observations = forward(true model) + N(0, 0.016 s), generated with the HIP path itself (synthetic data)
+    tt = rt.trace_device(torch.tensor(TRUE_V, device=dev, dtype=f64), torch.tensor(TRUE_D, device=dev, dtype=f64),
                          torch.tensor(off, device=dev), torch.tensor(dep, device=dev)).cpu().numpy()
-    ev = T.GpuEvaluator(off, dep, tt + rng.normal(0, 0.016, nsrc))
-    nloc = 32
-    s = T.NativeSampler(T.Prior(kmax=args.kmax), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
-                  rank=rank, world=world, dist=dist if world > 1 else None,
-                  dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
-    s.init_from_model(np.column_stack([[0.0] + d, v]), 0.016)
+    return off, dep, tt + rng.normal(0, 0.016, nsrc)
 
+
+def run_pt(rt, torch, dist, rank, world, dev, nsrc, kmax, steps, warmup):
+    """`steps` timed sweeps of 32 tempered chains per rank over nsrc shared sources, a swap round after every sweep.  Returns
+    a dict with the wall time (MAX over ranks), the sampler's counters over the timed region and the final ladder."""
+    from raytracerfortran_amd import tempering as T
+    off, dep, obs = pt_problem(torch, rt, dev, nsrc)
+    ev = T.GpuEvaluator(off, dep, obs)
+    nloc = 32
+    s = T.NativeSampler(T.Prior(kmax=kmax), ev, ndata=nsrc, nchains_total=nloc * world, nptchains1=world, dTlog=1.15, seed=7,
+                        rank=rank, world=world, dist=dist if world > 1 else None,
+                        dist_device=str(dev) if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+    s.init_from_model(np.column_stack([[0.0] + TRUE_D, TRUE_V]), 0.016)
     device_loop = world == 1 or s.comm is not None
     if device_loop:
         # sweeps + swap rounds enqueued back to back by ONE library call per timed region: no host synchronisation
@@ -420,42 +492,68 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
             for _ in range(n):
                 s.sweep()
                 s.swap_round()
-
-    run_steps(args.warmup)
+    run_steps(warmup)
     st0 = s.native.stats()
     tr0, ca0 = s.native.likelihood_counts()
-    elapsed, _ = timed_steps(None, args.steps, 0, world, dist if world > 1 else None, dev,
-                             sync=torch.cuda.synchronize, run_steps=run_steps)
+    sp0 = s.native.speculation()
+    elapsed, _ = timed_steps(None, steps, 0, world, dist if world > 1 else None, dev, sync=torch.cuda.synchronize, run_steps=run_steps)
     st1 = s.native.stats()
     tr1, ca1 = s.native.likelihood_counts()
-    models = st1["models"] - st0["models"]
-    launches = st1["launches"] - st0["launches"]
+    sp1 = s.native.speculation()
     s.sync()
+    red = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    tot = np.array([st1["models"] - st0["models"], tr1 - tr0, ca1 - ca0, sp1["discarded"] - sp0["discarded"]], dtype=np.float64)
     if world > 1:
-        tm = torch.tensor([float(models)], dtype=torch.float64,
-                          device=dev if dist.get_backend() == "nccl" else "cpu")
+        tm = torch.tensor(tot, dtype=torch.float64, device=red)
         dist.all_reduce(tm)
-        models = float(tm[0])
+        tot = tm.cpu().numpy()
+    launches = st1["launches"] - st0["launches"]
+    engine = ("one persistent cooperative launch per sweep" if launches <= 2 * max(1, steps)
+              else "two launches per proposal slot / pass, replayed as a hipGraph")
+    exchange = ("RCCL all-gather of 8 B per chain (rtmi_pt_swap_round)" if s.comm is not None
+                else ("every chain local: no collective" if world == 1 else "host gather (gloo rehearsal)"))
+    return {"elapsed": elapsed, "models": float(tot[0]), "traced": float(tot[1]), "cached": float(tot[2]), "discarded": float(tot[3]),
+            "launches": launches, "engine": engine, "exchange": exchange, "level": s.level, "nloc": nloc, "speculation_rows": sp1["rows"],
+            "rccl_ranks": s.comm.size() if s.comm is not None else 1, "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"]),
+            "red_device": red}
+
+
+def bench_pt(args, rt, torch, dist, rank, world, dev):
+    """Parallel-tempering sweeps (raytracerfortran_amd/tempering.py, device-resident sweep csrc/rtmi_pt.hip): 32 chains per GPU over 1e4 shared sources
+    (BASELINE config 3 on one GPU; config 4's sharding with N GPUs), k in [1, 10], swap round every sweep with the
+    logL all-gather over RCCL.  A "step" is one sweep of every chain; value = travel times TRACED per second (sources a
+    proposal does not affect are served from the chain's residual cache and are not counted; `delivered` counts them)."""
+    nsrc = 10_000 if args.nsrc == 1_000_000 else args.nsrc
+    r = run_pt(rt, torch, dist, rank, world, dev, nsrc, args.kmax, args.steps, args.warmup)
     if rank == 0:
-        res = {"metric": "travel-times/sec", "value": models * nsrc / elapsed, "unit": "travel-times/s",
+        elapsed, models = r["elapsed"], r["models"]
+        seen = r["traced"] + r["cached"]
+        traced_tt = r["traced"] if seen > 0 else models * nsrc   # (incremental likelihood off: every source of every model is traced)
+        res = {"metric": "travel-times/sec", "value": traced_tt / elapsed, "unit": "travel-times/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "ranks": world, "devices": args.devices, "collective_backend": args.backend,
+               "delivered_travel_times_per_s": models * nsrc / elapsed,
                "config": {"workload": "PT-RJMCMC sweeps: 32 tempered chains per GPU x %d shared sources, k in [1,%d], "
                                       "swap round every sweep (BASELINE configs 3/4 shape)" % (nsrc, args.kmax),
-                          "chains": nloc * world, "models_evaluated": models,
-                          "launches_per_step": launches / max(1, args.steps),
-                          "engine": "device-resident sweep (rtmi_pt_run), "
-                                    + ("one persistent cooperative launch per sweep" if launches <= 2 * max(1, args.steps)
-                                       else "two launches per proposal slot, replayed as a hipGraph") + ", swap exchange: "
-                                    + ("RCCL all-gather" if s.comm is not None else ("local" if world == 1 else "host gather (gloo rehearsal)")),
-                          "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"]),
-                          "sources_retraced_fraction": ((tr1 - tr0) / max(1, (tr1 - tr0) + (ca1 - ca0))) if (tr1 - tr0) + (ca1 - ca0) > 0 else 1.0,
+                          "chains": r["nloc"] * world, "models_decided": models, "models_evaluated_and_discarded": r["discarded"],
+                          "speculation_rows_per_chain": r["speculation_rows"],
+                          "launches_per_step": r["launches"] / max(1, args.steps),
+                          "engine": "device-resident sweep (rtmi_pt_run), " + r["engine"] + ", swap exchange: " + r["exchange"],
+                          "swap_accept_rate": r["swap_accept_rate"],
+                          "sources_retraced_fraction": (r["traced"] / seen) if seen > 0 else 1.0,
                           "likelihood": ("full: every proposal traced over all sources" if os.environ.get("RTMI_PT_INCREMENTAL") == "0"
                                          else "incremental: sources above the depth a proposal changes keep the residuals of the "
-                                              "chain's current model (bit-identical); value counts the travel times a full "
-                                              "evaluation delivers (models x sources), not only the re-traced ones")}}
+                                              "chain's current model (bit-identical).  `value` counts the travel times actually "
+                                              "traced (including those of speculated proposals that were discarded); "
+                                              "`delivered_travel_times_per_s` = decided models x sources, what a sampler that "
+                                              "evaluates every proposal in full has to trace for the same chain")},
+               "chain_parallel": chain_parallel_block(r["level"], r["rccl_ranks"], world, elapsed, args.steps, models, nsrc, r["nloc"],
+                                                      dist if world > 1 else None, r["red_device"], rccl_info(rt), r["engine"], r["exchange"])}
         print(json.dumps(res), flush=True)
+    else:
+        chain_parallel_block(r["level"], r["rccl_ranks"], world, r["elapsed"], args.steps, r["models"], nsrc, r["nloc"],
+                             dist if world > 1 else None, r["red_device"], {}, r["engine"], r["exchange"])  # (takes part in the all-reduce)
     if world > 1:
         dist.destroy_process_group()
 
@@ -469,6 +567,8 @@ def parse_args(argv=None):
     ap.add_argument("--kmax", type=int, default=10, help="pt: largest number of nodes of a chain (config 3: 10, config 4: 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the PCIe-inclusive drop-in figures (c2 only)")
+    ap.add_argument("--no-chain-parallel", action="store_true",
+                    help="c2: skip the chain_parallel block (100 sweeps of the tempering sampler with the RCCL swap exchange)")
     ap.add_argument("--check", action="store_true", help="also compare one step with the oracle")
     ap.add_argument("--workload", choices=["c2", "pt", "c4", "c5"], default="c2",
                     help="c2: single dff forward, 1e6 sources (the bench metric's configuration, default); "
@@ -542,6 +642,7 @@ def main():
                                    sync=torch.cuda.synchronize,
                                    make_event=lambda: torch.cuda.Event(enable_timing=True), stream=stream)
 
+    kernel_name = rt.last_kernel_name()  # what the timed launches dispatched (before anything else launches)
     check = None
     if args.check and rank == 0:
         from oracle import oracle as O
@@ -551,9 +652,17 @@ def main():
         check = {"max_abs_dt": float(np.abs(got[okm] - ref[okm]).max()),
                  "sentinel_mismatch": int(((got == -999.0) != (ref == -999.0)).sum())}
 
+    # The path's one exchange step, made visible to the scaling run (BASELINE configs 3/4): after the C2
+    # measurement every rank runs 100 sweeps of its 32 tempered chains over 1e4 shared sources through rtmi_pt_run with the
+    # LIBRARY's communicator -- one RCCL all-gather of 8 B per chain per swap round -- and the line carries what came of it.
+    cp = None
+    if not args.no_chain_parallel:
+        r = run_pt(rt, torch, dist, rank, world, dev, 10_000, 10, 100, 20)
+        cp = chain_parallel_block(r["level"], r["rccl_ranks"], world, r["elapsed"], 100, r["models"], 10_000, r["nloc"],
+                                  dist if world > 1 else None, r["red_device"], rccl_info(rt) if rank == 0 else {}, r["engine"], r["exchange"])
+
     if rank == 0:
         value = world * n * args.steps / elapsed
-        achieved = BYTES_PER_TT * n / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -562,36 +671,12 @@ def main():
             "config": {"workload": "C2: single dff forward, 1e6 sources x 8 interfaces (9 velocities, one LVZ), "
                                    "seed 12345; BASELINE.json configs[1]",
                        "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rtmi::fused_kernel<double, false, true, false, false, true>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
-                         "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; "
-                                 "see DESIGN.md section 4"},
         }
-        tr = measured_traffic()
-        if tr is not None and n == 1_000_000:
-            res["roofline"]["traffic"] = tr[0]
-            res["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-        # the roof that actually binds: the fp64 vector ALU.  One wave-instruction occupies a SIMD for 4 cycles
-        # (v_rsq/v_rcp_f64: 16), i.e. 16 lanes per clock and SIMD = FP64_VALU_PEAK_TFLOPS / 2 lane-instructions per
-        # second over the chip.  Executed instructions come from the same PMC passes (SQ_INSTS_VALU); the useful part
-        # is the layer terms the kernel still has to evaluate: 23.2 per travel time on this workload (19.1 in the solve
-        # loop, counted by the instrumented kernel, profiles/r03d/phase_clocks.txt, + the first evaluation of the 93 %
-        # of sources below the top layer) x 35 instructions each.  (The reference's own arithmetic makes 41.7 per
-        # travel time: nearly half of them are proven unnecessary)
-        peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
-        res["valu_fp64"] = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
-                            "useful_term_instr_per_travel_time": 23.2 * 35,
-                            "useful_frac_of_peak": 23.2 * 35 * value / peak_lane_instr,
-                            "note": "fp64 VALU issue is the binding roof (DESIGN.md section 4.2)"}
-        mc = measured_counters()
-        if mc is not None and mc[1] and n == 1_000_000 and kern_ms:
-            res["valu_fp64"]["executed_valu_wave_instr_per_launch"] = mc[1]
-            res["valu_fp64"]["executed_frac_of_peak"] = mc[1] * 64.0 / (kern_ms * 1e-3) / peak_lane_instr
-            res["valu_fp64"]["source"] = mc[2]
+        res["roofline"], res["valu_fp64"] = c2_roofline(n, kern_ms, kernel_name)
         if check is not None:
             res["check_vs_oracle"] = check
+        if cp is not None:
+            res["chain_parallel"] = cp
         if world == 1 and not args.no_dropin:
             res["dropin"] = dropin_figures(rt, v, d, off, dep, dt.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:

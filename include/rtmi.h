@@ -48,8 +48,9 @@ enum {
  * keep_delta > 0 additionally writes ./rays.dat (two records per ray: horizontal
  * segment lengths, then segment thicknesses; subroutineR-quiet.f90:98-105,157-164).
  * No status is returned (the reference has none): on a device failure the call
- * prints the reason to stderr, fills timeP with NaN and aborts the process unless
- * RTMI_ABORT_ON_ERROR=0 is set in the environment.
+ * prints the reason to stderr and fills timeP with NaN -- loud, never a plausible
+ * number, and an R session that loaded the library survives it.
+ * RTMI_ABORT_ON_ERROR=1 in the environment makes it abort the process instead.
  */
 void dff_(const double *vels, const double *depths, const int *NLayers, double *src_offset,
           double *src_depth, const int *NSrc, double *timeP, const int *keep_delta);
@@ -112,7 +113,7 @@ int rtmi_loglhood_batch(const double *vels, const double *depths, const int32_t 
  * The likelihood of a proposal is INCREMENTAL: a birth, death or perturbation changes the model from some depth
  * downwards, and a source above that depth has, bit for bit, the travel time it has under the chain's current model --
  * its squared residual is taken from a per-chain cache in HBM (2 x nchains x ndata doubles) instead of being traced
- * again.  The sampler's sums of squared residuals are ORDER-INDEPENDENT (integer sums on a fixed 2^-76 s^2 grid, per lane, wave, workgroup),
+ * again.  The sampler's sums of squared residuals are ORDER-INDEPENDENT (integer sums on a fixed 2^-64 s^2 grid -- addends below 2^32 s^2, so that the reference's -999 sentinel stays a finite residual --, per lane, wave, workgroup),
  * so their value does not depend on the order of the additions: logL and the chains are those of the full evaluation
  * (RTMI_PT_INCREMENTAL=0 evaluates every proposal over all sources), whatever the launch geometry, knobs or engine.
  *   EXPLORE_MH_NOVARPAR  prjmh_temper_rf.f90:637-761   BIRTH_FULL :997  DEATH_FULL :917  PROPOSAL :1387
@@ -205,6 +206,10 @@ int rtmi_comm_unique_id(char id[RTMI_COMM_ID_BYTES]);
 rtmi_comm *rtmi_comm_create(int nranks, int rank, const char id[RTMI_COMM_ID_BYTES]);
 void rtmi_comm_destroy(rtmi_comm *comm);
 int rtmi_comm_size(const rtmi_comm *comm);
+/* which RCCL the communicator is: ncclGetVersion (-1 on failure) and the path of the shared object ncclAllGather resolves to
+ * inside this library (a process that holds torch carries a second copy; load order decides) */
+int rtmi_comm_rccl_version(void);
+int rtmi_comm_rccl_library(char *path, int cap);
 int rtmi_comm_rank(const rtmi_comm *comm);
 /* all-gather of `count` doubles per rank, device pointers, asynchronous on `stream` */
 int rtmi_comm_allgather_f64(rtmi_comm *comm, const double *d_send, double *d_recv, int64_t count, void *stream);
@@ -234,6 +239,9 @@ int rtmi_device_status(void);
 int rtmi_clear_device_status(void);
 /* Number of compute units of the bound device (256 on MI355X); 0 on failure. */
 int rtmi_device_cus(void);
+/* Name of the kernel the calling thread's last forward / batch launch dispatched, spelled as rocprofv3 --kernel-trace prints it
+ * ("" before the first launch): lets a measurement name the kernel it timed instead of assuming it. */
+const char *rtmi_last_kernel_name(void);
 /*
  * Scheduling knobs of rtmi_trace_device (never change results, only speed); process-wide.
  *   "path"            0 auto (default), 1 always the plain kernel, 2 always the fused kernel

@@ -27,6 +27,7 @@
  *   - constants 0.1, 15, 20, 1e-9, 1e-10, 1e-12 exactly as in the source.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -360,6 +361,31 @@ int SYM(oracle_ray_segments)(const real_t *vels, const real_t *depths, int nlaye
 }
 
 #ifndef ORACLE_F32
+#ifndef ORACLE_F32
+/*
+ * SUM(DresRT**2) of many models over one source set: what LOGLHOOD_RT leaves in SUM((DobsRT - DpredRT)**2) for each of
+ * nmodels calls (loglhood.f90:128-146, :165-166, :195), in source order.  V / D rows of ld doubles, NL[m] interfaces.  Used
+ * by the quadrature of the posterior tests (tests/golden/make_posterior_golden.py); test infrastructure like the rest.
+ */
+void oracle_ss_batch(const double *V, const double *D, const int32_t *NL, int ld, int64_t nmodels, const double *src_offset,
+                     const double *src_depth, const double *obs, int64_t nsrc, double *ss)
+{
+    double *t = (double *)malloc((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(double));
+    if (!t)
+        return;
+    for (int64_t m = 0; m < nmodels; ++m) {
+        oracle_dff(V + m * ld, D + m * ld, NL[m], src_offset, src_depth, nsrc, t, NULL, NULL);
+        double s = 0.0;
+        for (int64_t k = 0; k < nsrc; ++k) {
+            const double r = obs[k] - t[k];
+            s = s + r * r;
+        }
+        ss[m] = s;
+    }
+    free(t);
+}
+#endif
+
 /*
  * Gaussian travel-time log-likelihood of one model, as LOGLHOOD_RT computes it
  * (/root/reference/ray_tracing_sampling/loglhood.f90:165-199, ICOV=1 branch):

@@ -68,6 +68,9 @@ def _oracle_lib():
         lib.oracle_ray_segments.restype = ctypes.c_int
         lib.oracle_loglhood_rt.argtypes = [_c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int]
         lib.oracle_loglhood_rt.restype = ctypes.c_double
+        lib.oracle_ss_batch.argtypes = [_c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int64,
+                                        _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p]
+        lib.oracle_ss_batch.restype = None
         _lib = lib
     return _lib
 
@@ -124,6 +127,18 @@ def oracle_loglhood_rt(obs, pred, sd, stable: bool = False) -> float:
 
 
 _lib32 = None
+
+
+def oracle_ss_batch(V, D, NL, src_offset, src_depth, obs):
+    """SUM(DresRT**2) of every model row over one source set (one LOGLHOOD_RT call per model, loglhood.f90:128-199)."""
+    V, D = _f64(V), _f64(D)
+    NL = np.ascontiguousarray(NL, dtype=np.int32)
+    off, dep, obs = _f64(src_offset), _f64(src_depth), _f64(obs)
+    assert V.ndim == 2 and V.shape == D.shape and NL.size == V.shape[0] and off.size == dep.size == obs.size
+    ss = np.empty(V.shape[0])
+    _oracle_lib().oracle_ss_batch(_p(V), _p(D), NL.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), V.shape[1], V.shape[0],
+                                  _p(off), _p(dep), _p(obs), off.size, _p(ss))
+    return ss
 
 
 def oracle_dff_f32(vels, depths, src_offset, src_depth, want_p: bool = False):

@@ -31,5 +31,13 @@ for k, c in out.items():
         fetch = c["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2  # gfx950: doubled (see module docstring)
         write = c["WRITE_SIZE"]["mean_per_launch"] * 1024
         c["hbm_bytes_per_launch"] = {"read_corrected": fetch, "write": write, "total": fetch + write}
+# which build these counters belong to (bench.py quotes it next to figures it did not measure itself)
+try:
+    import subprocess
+    head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "--", "raytracerfortran_amd/csrc"]) != 0
+    out["build_commit"] = head + (" + uncommitted changes to csrc/" if dirty else "")
+except Exception:
+    out["build_commit"] = "unknown"
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -6,7 +6,7 @@ One hot path, behind the reference's own call boundary:
 Kernels and the C ABI live in csrc/ and are built in-tree into librtmi.so by build.py.
 """
 from . import raymod  # noqa: F401
-from .raymod import (RtmiError, TraceRays, dff, dff7, dofullforwardproblem, init, load_library, loglhood_batch, set_option, set_sources,  # noqa: F401
-                     trace_batch_device, trace_device, write_rays_dat)
+from .raymod import (RtmiError, TraceRays, comm_rccl_library, comm_rccl_version, dff, dff7, dofullforwardproblem, init, last_kernel_name,  # noqa: F401
+                     load_library, loglhood_batch, set_option, set_sources, trace_batch_device, trace_device, write_rays_dat)
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -187,7 +187,7 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc, double *d_timeP,
                  const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out, hipStream_t stream,
                  const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts,
-                 unsigned long long *d_partial_x, int part_stride)
+                 unsigned long long *d_partial_x, int part_stride, int acc_atomic, const rtmi::PtPend *d_pinfo)
 {
     const Tuning tn = tuning_snapshot();
     int *d_status = nullptr;
@@ -217,6 +217,8 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
         if (d_partial_x && d_obs && !d_timeP) {  // the sampler's form of the sums (exact), optionally incremental
             fa.d_partial_x = d_partial_x;
             fa.part_stride = part_stride;
+            fa.acc_atomic = acc_atomic;
+            fa.d_pinfo = d_pinfo;
             if (d_inc && d_r2) {
                 fa.d_inc = d_inc;
                 fa.d_r2 = d_r2;
@@ -296,6 +298,56 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
         (void)hipGetLastError();  // not sticky: the caller falls back
         if (getenv("RTMI_PT_VERBOSE"))
             fprintf(stderr, "rtmi: persistent sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
+        return -1;
+    }
+    return RTMI_OK;
+}
+
+int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,
+                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus,
+                    const void *ptdev, size_t ptdev_bytes, const void *d_queue_args, int nspec, unsigned int fin_target, int task_src,
+                    hipStream_t stream,
+                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
+                    int part_stride, const rtmi::PtPend *d_pinfo)
+{
+    const Tuning tn = tuning_snapshot();
+    if (!batch_takes_fused(tn, nsrc) || !d_partial_x)
+        return -1;
+    int *d_status = nullptr;
+    int rc = status_word_for(stream, &d_status);
+    if (rc)
+        return rc;
+    rtmi::FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.d_vels = d_vels;
+    fa.d_depths = d_depths;
+    fa.d_nlayers = d_nlayers;
+    fa.ld_model = ld_model;
+    fa.refill_min = tn.refill_min;
+    fa.tail_group = tn.tail_group;
+    fa.retire_max = tn.retire_max;
+    fa.d_status = d_status;
+    fa.promote_age = tn.promote_age;
+    fa.allow_skip = 1;
+    fa.d_src_offset = d_src_offset;
+    fa.d_src_depth = d_src_depth;
+    fa.nsrc = nsrc;
+    fa.d_obs = d_obs;
+    fa.d_partial_x = d_partial_x;
+    fa.part_stride = part_stride;
+    fa.acc_atomic = 1;
+    fa.d_pinfo = d_pinfo;
+    if (d_inc && d_r2) {
+        fa.d_inc = d_inc;
+        fa.d_r2 = d_r2;
+        fa.d_inc_counts = d_inc_counts;
+    }
+    const hipError_t e = rtmi_launch_pt_queue(&fa, ptdev, ptdev_bytes, static_cast<const rtmi::PtQueueArgs *>(d_queue_args), nspec,
+                                              fin_target, max_nlayers, cus, tn.solve_waves, task_src, stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the caller falls back
+        if (getenv("RTMI_PT_VERBOSE"))
+            fprintf(stderr, "rtmi: queue sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
         return -1;
     }
     return RTMI_OK;
@@ -645,8 +697,10 @@ void dropin_failed(const char *who, double *timeP, int nsrc)
     if (timeP)
         for (int i = 0; i < nsrc; ++i)
             timeP[i] = NAN;
+    // an R session (or any host program) that loads the library survives a device failure: the reason is on stderr and
+    // every output is NaN -- never a plausible number.  RTMI_ABORT_ON_ERROR=1 asks for the hard stop instead.
     const char *e = getenv("RTMI_ABORT_ON_ERROR");
-    if (!e || strcmp(e, "0") != 0)
+    if (e && strcmp(e, "0") != 0)
         abort();
 }
 

@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
+#include <cstdio>
 #include <cstring>
 
 #include "rtmi_host.h"
@@ -83,6 +86,28 @@ void rtmi_comm_destroy(rtmi_comm *comm)
 }
 
 int rtmi_comm_size(const rtmi_comm *comm) { return comm ? comm->nranks : 1; }
+
+// Which RCCL this library's communicator is: a process that also holds torch carries torch's bundled librccl next to the
+// system one this library is linked against, and which of them ncclCommInitRank / ncclAllGather resolve to INSIDE librtmi.so is
+// decided by load order (raymod.py imports torch first, so that one copy serves both).  Version as ncclGetVersion reports it;
+// path of the shared object the symbol lives in (dladdr).
+int rtmi_comm_rccl_version(void)
+{
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : -1;
+}
+
+int rtmi_comm_rccl_library(char *path, int cap)
+{
+    if (!path || cap < 2)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_comm_rccl_library: bad argument");
+    Dl_info info;
+    memset(&info, 0, sizeof info);
+    if (!dladdr(reinterpret_cast<const void *>(&ncclAllGather), &info) || !info.dli_fname)
+        return fail(RTMI_ERR_HIP, "rtmi_comm_rccl_library: dladdr found no object for ncclAllGather");
+    snprintf(path, (size_t)cap, "%s", info.dli_fname);
+    return RTMI_OK;
+}
 
 int rtmi_comm_rank(const rtmi_comm *comm) { return comm ? comm->rank : 0; }
 

@@ -663,14 +663,18 @@ __device__ __forceinline__ int hi_word(double v) { return __double2hiint(v); }
 __device__ __forceinline__ int hi_word(float v) { return (int)__float_as_uint(v); }
 
 // ---- order-independent accumulation of squared residuals (the sampler's likelihood) ---------------------------------------
-// A 124-bit fixed-point accumulator in two words, least significant bit 2^-76 s^2: an addend (>= 0, below 2^20 s^2) is cut to
-// that grid -- a fixed function of the addend alone, |error| < 1.4e-23 s^2, twenty orders below a double's resolution of a
-// chain's sum -- and added as an integer, and integer addition is associative: the sum of a chain's squared residuals does
-// not depend on the order in which lanes, waves, workgroups or launches of different geometry add them up, nor on whether a
-// residual was computed in this launch or taken from the chain's cache.  The two top bits of the high word are flags (the
-// sum itself stays below 2^50 s^2: fewer than 2^30 addends): bit 63 = a NaN was added (the sum is NaN, as the reference's
-// SUM would be), bit 62 = an addend >= 2^20 s^2 (the sum is reported as +Inf).  [Four registers per lane; the 192-bit form
-// of round 2, exact down to 2^-128, took seven and pushed the sampler's kernel into scratch.]
+// A 126-bit fixed-point accumulator in two words, least significant bit 2^-64 s^2: w0 holds the fraction, w1 the integer part
+// (62 bits) and two flags.  An addend (>= 0, below 2^32 s^2) is ROUNDED to that grid -- a fixed function of the addend alone,
+// |error| <= 2^-65 = 2.7e-20 s^2, unbiased -- and added as an integer, and integer addition is associative: the sum of a
+// chain's squared residuals does not depend on the order in which lanes, waves, workgroups or launches of different geometry
+// add them up, nor on whether a residual was computed in this launch or taken from the chain's cache.  The two top bits of
+// the high word are flags (the sum itself stays below 2^62 s^2: 2^30 addends of the largest size): bit 63 = a NaN was added
+// (the sum is NaN, as the reference's SUM would be), bit 62 = an addend >= 2^32 s^2 (the sum is reported as +Inf).
+// [Round 3 had the grid at 2^-76 with addends below 2^20 s^2 -- which the reference's own -999 sentinel exceeds as soon as an
+// observed time is above 25 s: (t_obs + 999)^2 >= 2^20.  The reference sums that residual as a finite 1e6 (loglhood.f90:191
+// with GetPTime's -999), and so do the batch API and the host sampler; with the grid here the sentinel's residual stays
+// finite for every observed time below 64 000 s.  Four registers per lane; the 192-bit form of round 2, exact down to
+// 2^-128, took seven and pushed the sampler's kernel into scratch.]
 struct Acc192 {  // (the name of the round-2 form is kept)
     unsigned long long w0, w1;
 };
@@ -702,7 +706,7 @@ __device__ __forceinline__ void acc_add_double(Acc192 &a, double x)
         a.w1 |= RTMI_ACC_NAN;
         return;
     }
-    if (x >= 1048576.0) {  // 2^20
+    if (x >= 4294967296.0) {  // 2^32
         a.w1 |= RTMI_ACC_INF;
         return;
     }
@@ -711,14 +715,14 @@ __device__ __forceinline__ void acc_add_double(Acc192 &a, double x)
     if (e == 0)
         return;  // zero or subnormal: below the grid
     unsigned long long m = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;  // x = m 2^(e - 1075)
-    int shift = e - 999;                                                      // position of m's lowest bit above 2^-76
+    int shift = e - 1011;                                                     // position of m's lowest bit above 2^-64
     if (shift < 0) {
-        if (shift <= -53)
-            return;
-        m >>= -shift;  // cut to the grid
+        if (shift < -53)
+            return;  // below half a grid step
+        m = (m + (1ull << (-shift - 1))) >> -shift;  // round to the grid (ties up)
         shift = 0;
     }
-    // x < 2^20: shift <= 43, so m << shift ends below bit 96
+    // x < 2^32: shift <= 43, so m << shift ends below bit 96
     const unsigned long long lo = m << shift;
     const unsigned long long hi = shift ? m >> (64 - shift) : 0ull;
     const unsigned long long t = a.w0 + lo;
@@ -734,7 +738,7 @@ __device__ __forceinline__ double acc_to_double(const Acc192 &a)
         return __builtin_nan("");
     if (a.w1 & RTMI_ACC_INF)
         return __builtin_inf();
-    return __ull2double_rn(a.w1) * 2.44140625e-4 + __ull2double_rn(a.w0) * 1.3234889800848443e-23;  // 2^-12, 2^-76
+    return __ull2double_rn(a.w1) + __ull2double_rn(a.w0) * 5.421010862427522e-20;  // 2^-64
 }
 
 // lower end of the guarded range of w = 1 - p^2 v^2

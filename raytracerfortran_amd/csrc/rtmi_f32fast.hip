@@ -197,7 +197,10 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
         for (int q0 = (threadIdx.x & ~63); q0 < nvalid; q0 += F32F_BLOCK) {
             const int q = q0 + lane;
             const bool valid = q < nvalid;
-            const float zq = valid ? sz[q] : 1.0f, Rq = valid ? sR[q] : 1.0f;
+            // costFunc is odd in p (subroutineR-quiet.f90:184-202), so a source at offset -R has the mirror ray of the one at R:
+            // the same travel time, the ray parameter with the opposite sign -- solved for |R| (the tolerances below are relative to it)
+            const float Rs = valid ? sR[q] : 1.0f;
+            const float zq = valid ? sz[q] : 1.0f, Rq = __builtin_fabsf(Rs);
             const uint32_t rec = valid ? sidx[q] : 0u;
             const int ilq = (int)(rec >> 16);  // the record's layer
             float tt, pp = __builtin_nanf("");
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
             if (valid) {
                 const int loc = (int)(rec & 0xFFFFu);
                 tout[loc] = tt;
-                pout[loc] = pp;
+                pout[loc] = Rs < 0.0f ? -pp : pp;
             }
         }
         __syncthreads();

@@ -78,7 +78,8 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
                  int max_nlayers, const double *d_src_offset, const double *d_src_depth, int64_t nsrc,
                  double *d_timeP, const double *d_obs, double *d_partial, bool allow_skip, int cus, int *gx_out,
                  hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2 = nullptr,
-                 unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0);
+                 unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0,
+                 int acc_atomic = 0, const rtmi::PtPend *d_pinfo = nullptr);
 // whether launch_batch takes the fused kernel for this many sources (current knobs)
 bool batch_is_fused(int64_t nsrc);
 // workgroups per model (= partial sums per model) launch_batch will use for this shape
@@ -91,6 +92,15 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
                     const double *d_obs, double *d_partial, int cus, const void *ptdev, size_t ptdev_bytes,
                     const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2 = nullptr,
                     unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0);
+
+// The speculative sweep over a task queue (rtmi_kernels.hip::pt_sweep_queue_kernel): an ordinary launch of one workgroup per
+// CU.  Non-zero = not available (the plain kernel path is selected): use the per-slot launches.
+int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,
+                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus,
+                    const void *ptdev, size_t ptdev_bytes, const void *d_queue_args, int nspec, unsigned int fin_target, int task_src,
+                    hipStream_t stream,
+                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
+                    int part_stride, const rtmi::PtPend *d_pinfo);
 
 }  // namespace rtmi_host
 

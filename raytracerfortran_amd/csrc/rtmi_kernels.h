@@ -63,7 +63,14 @@ struct PtInc {
     int mover;
     int cur_row, pend_row, prop_row;
     int n0, pn0;
-    int pad_;
+    int pend_idx;   // > 0: the pending proposal's record is d_pinfo[pend_idx - 1] (its zthr, dl1, dl2, n0, prop_row stand for
+                    // pzthr, pdl1, pdl2, pn0, pend_row): the speculative step names the accepted entry instead of copying it
+};
+// What a later launch needs to know about an ACCEPTED proposal whose residuals are still in its own row (PtInc::pend_idx):
+// written when the proposal is made, one record per model row and per set of proposal rows.
+struct PtPend {
+    double zthr, dl1, dl2;
+    int n0, prop_row;
 };
 
 // Arguments of the fused large-NSrc kernel.  Model m = blockIdx.y uses row m of d_vels / d_depths.
@@ -101,6 +108,9 @@ struct FusedArgsT {
     T *d_r2;                       // residual slab of the incremental likelihood: rows of nsrc squared residuals (PtInc names the rows)
     unsigned long long *d_inc_counts;  // [nmodels][part_stride][2] or NULL: sources traced / taken from the cache, added up over the launches
     int part_stride;               // words of d_partial_x / d_inc_counts per model row are indexed [m][part_stride]; 0 = the launch's grid.x
+    int acc_atomic;                // the sampler's form: a row's workgroups ADD their exact sums into d_partial_x[m][0] (three limbs of 48
+                                   // bits + the flags, 64-bit atomics: integer addition commutes) instead of writing a slot each
+    const PtPend *d_pinfo;         // records of accepted proposals (PtInc::pend_idx) or NULL
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };
@@ -122,6 +132,28 @@ struct PtSweepArgs {
                            // chain runs passes until its sweep is complete (nslots_k only bounds them), `epoch` is a tag of
                            // the sweep (the passes of a sweep count from it, at most 4096)
 };
+
+// Arguments of the tempering sampler's sweep as a persistent kernel over a TASK QUEUE (pt_sweep_queue_kernel): workgroups are
+// not bound to chains.  A task = one share (sub of nw) of one model row's sources; the step of a chain is taken by whichever
+// workgroup finishes the last task of the chain's window, and publishes the next window's tasks.
+#define RTMI_PTQ_RINGS 2  // priority classes: ring 0 is served first
+struct PtQueueArgs {
+    unsigned long long *slots;  // [RTMI_PTQ_RINGS][qmask + 1] (ticket + 1) << 32 | task word, published with release
+    unsigned int *ctl;          // ring r: tail (tickets produced) at ctl[32 r], head (tickets claimed) at ctl[32 r + 16]; never reset
+    unsigned int *pendcnt;      // [nchains] tasks of the chain's window that are still out
+    unsigned int *rem;          // [nchains] proposal slots the chain still has to decide in this sweep (priority: longest first)
+    unsigned int *nfinished;    // chains whose sweep is complete, counted over all launches (a launch is told where its sweep ends)
+    unsigned int *abort_;       // [1] set when a bounded wait ran out: every workgroup leaves at its next wait
+    unsigned int qmask;         // ring size - 1 (power of two, larger than the tasks that can be out at once)
+    int nchains;
+    int nspec;                  // model rows per chain (rtmi_pt_dev.hpp::pt_step_spec)
+    int task_fine, task_coarse; // sources per task when workgroups are idle / when the rings are backed up
+    unsigned long long *stats;  // NULL, or [8] diagnostic sums over workgroups and launches: ticks (100 MHz) in tasks, in steps, waiting
+                                // for a task; tasks; steps; workgroup lifetimes (RTMI_PT_QSTATS)
+};
+#define RTMI_PTQ_POISON 0x80000000u   // ptq_take: the sweep is complete (or aborted), the workgroup leaves
+#define RTMI_PTQ_WORD(chain, e, sub, nw) ((unsigned int)(chain) | ((unsigned int)(e) << 16) | ((unsigned int)(sub) << 19) | ((unsigned int)((nw) - 1) << 25))
+#define RTMI_PTQ_MAX_NW 64            // shares per row (6 bits)
 
 // Arguments of the single-precision fast forward model (rtmi_f32fast.hip).  Sorted interfaces, positive velocities.
 #define RTMI_F32FAST_MAX_NL 63
@@ -157,6 +189,12 @@ hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_n
 hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
                                 const rtmi::PtSweepArgs *w, int nchains, int max_nlayers, int num_cus,
                                 int waves_per_simd, hipStream_t stream);
+// The queue form of the sweep: an ordinary launch of one workgroup per CU (no co-residency needed: a workgroup only ever
+// waits for a ticket whose task running workgroups will produce).  d_q: DEVICE copy of the queue's (constant) words;
+// fin_target: value of *nfinished at which this launch's sweep is complete; task_src: sources per task the LDS is sized for.
+hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtQueueArgs *d_q,
+                                int nspec, unsigned int fin_target, int max_nlayers, int num_cus, int waves_per_simd, int task_src,
+                                hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
                                           unsigned long long *d_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,

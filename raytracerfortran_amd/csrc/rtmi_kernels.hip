@@ -49,6 +49,7 @@
 //  Both kernels are templates on the scalar type: double is the reference's precision, float the
 //  fp32 path of BASELINE config 5 (its layer term has a guarded form of its own, everything else is IEEE).
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -250,9 +251,15 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                                            WANT_T ? a.d_timeP + (int64_t)m * a.nsrc : nullptr, a.nsrc,
                                            (WANT_SS && !INC) ? a.d_partial + ((int64_t)m * gx + bx) : nullptr, bx, gx)) {
         if (INC && threadIdx.x == 0) {
-            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
-            o[0] = o[2] = o[3] = 0ull;
-            o[1] = (a.allow_skip && a.nlayers == 0) ? 0ull : RTMI_ACC_NAN;  // an unusable row: NaN, like the plain form
+            const bool skip = a.allow_skip && a.nlayers == 0;
+            if (a.acc_atomic) {
+                if (!skip)  // an unusable row: NaN, like the plain form
+                    __hip_atomic_fetch_or(a.d_partial_x + 4 * ((int64_t)m * pstride) + 3, RTMI_ACC_NAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
+                o[0] = o[2] = o[3] = 0ull;
+                o[1] = skip ? 0ull : RTMI_ACC_NAN;
+            }
         }
         return;
     }
@@ -269,6 +276,14 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
     int64_t n0 = 0;  // (SORTED) sources [0, n0) are not loaded: their residuals come from the cache
     if (inc) {
         ic = a.d_inc[m];
+        if (ic.pending && ic.pend_idx > 0) {  // the pending proposal's own record
+            const PtPend pp = a.d_pinfo[ic.pend_idx - 1];
+            ic.pzthr = pp.zthr;
+            ic.pdl1 = pp.dl1;
+            ic.pdl2 = pp.dl2;
+            ic.pn0 = pp.n0;
+            ic.pend_row = pp.prop_row;
+        }
         r2cur = a.d_r2 + (int64_t)ic.cur_row * a.nsrc;
         r2pend = a.d_r2 + (int64_t)ic.pend_row * a.nsrc;
         r2prop = a.d_r2 + (int64_t)ic.prop_row * a.nsrc;
@@ -1221,15 +1236,32 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 tr += wx[4 * w + 2];
                 ca += wx[4 * w + 3];
             }
-            unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
-            o[0] = tot.w0;
-            o[1] = tot.w1;
-            o[2] = 0ull;
-            o[3] = 0ull;
+            if (a.acc_atomic) {
+                // the row's accumulator: limbs of 48 bits in 64-bit words (no carry between words until 2^16 sums are in)
+                unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride);
+                const unsigned long long v1 = tot.w1 & ~RTMI_ACC_FLAGS, fl = tot.w1 & RTMI_ACC_FLAGS;
+                __hip_atomic_fetch_add(o + 0, tot.w0 & 0xFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(o + 1, (tot.w0 >> 48) | ((v1 & 0xFFFFFFFFull) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(o + 2, v1 >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fl)
+                    __hip_atomic_fetch_or(o + 3, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                unsigned long long *o = a.d_partial_x + 4 * ((int64_t)m * pstride + bx);
+                o[0] = tot.w0;
+                o[1] = tot.w1;
+                o[2] = 0ull;
+                o[3] = 0ull;
+            }
             if (counting) {
-                unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride + bx);
-                oc[0] += tr;
-                oc[1] += ca;
+                if (a.acc_atomic) {  // (a row's shares are not bounded by pstride here)
+                    unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride);
+                    __hip_atomic_fetch_add(oc + 0, tr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(oc + 1, ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride + bx);
+                    oc[0] += tr;
+                    oc[1] += ca;
+                }
             }
         }
     } else if (WANT_SS) {
@@ -1332,95 +1364,280 @@ __device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int
     }
 }
 
-// The speculative form of the persistent sweep (rtmi_pt_dev.hpp::pt_step_spec): a chain's gx workgroups run PASSES until the
-// chain's sweep is complete.  Per pass the leading workgroup takes the step -- the decisions of the window evaluated in the
-// pass before, the sigma move once every slot is decided, the next window of up to nspec proposals -- and publishes it; the
-// chain's workgroups then deal themselves to the rows that go through the likelihood (workgroup w evaluates the a-th such
-// row, a = w mod nact, as workgroup w / nact of ceil((gx - a) / nact): the sums are exact, so how many workgroups add a row
-// up changes nothing), write their sums and arrive.  A window of proposals that all lie below the deepest source needs no
-// pass at all: the leading workgroup takes the next step at once.
-template <int TF, bool INCR>
-__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_spec_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, PtSweepArgs w)
+// ---- the speculative sweep over a TASK QUEUE ------------------------------------------------------------------------
+// With the speculative step (rtmi_pt_dev.hpp::pt_step_spec) a pass of a chain -- up to nspec model rows side by side -- is as
+// much work as the machine's share of a chain can take, and what is left on the table is the IMBALANCE between chains: a
+// sweep ends when the chain with the most nodes (most slots) has run its last pass, and workgroups bound to chains that were
+// done early idle for the rest of it.  Here no workgroup belongs to a chain:
+//   task   one share (sub of nw) of the sources of one model row: fused_body(row, sub, nw).  The sums are exact integers and
+//          a row's workgroups add theirs into the row's accumulator, so into how many shares a row is cut decides nothing.
+//   rings  task words in HBM, one ring per priority class.  A producer reserves tickets (atomic add on the ring's tail) and
+//          publishes each slot as (ticket + 1) << 32 | word with release; a consumer claims the next ticket of the first ring
+//          that has one (compare-and-swap on its head) and reads exactly that slot.  Tickets only grow, from launch to launch.
+//   order  LONGEST CHAIN FIRST: what bounds a sweep is the chain with the most slots left (its passes are sequential), so a
+//          chain within one window of the largest number of slots still to decide publishes to ring 0, the others to ring 1.
+//   size   a row is cut into tasks of task_fine sources while workgroups are idle (no backlog in the rings), of task_coarse
+//          sources when the rings are backed up (fewer, larger tasks: less of the per-task table staging).
+//   step   a chain's window is complete when its counter of outstanding tasks falls to zero: the workgroup that takes it
+//          there takes the chain's step at once -- decisions of the window, sigma move, next window (pt_step_spec) -- and
+//          publishes the next window's tasks; a window without tasks (every proposal below the deepest source) is stepped
+//          over on the spot.  The first step of every chain is taken at the start of the kernel.
+//   end    a workgroup that finds no task leaves once every chain's sweep is complete (a counter of finished chains).
+// A workgroup never waits for anything but a slot it has claimed after its ticket was reserved, so no co-residency is
+// needed: the launch is an ordinary one.  Every wait is bounded all the same (abort word + bit 16 of the fault word).
+// How a workgroup comes by its next task.  Ring 0 is a TICKET ring: a claim is one atomic add on its head and always
+// succeeds; a workgroup without work holds a ticket and polls the slot that belongs to it alone -- two hundred idle workgroups
+// do not touch one shared word (a compare-and-swap design, in which every idle workgroup watches head and tail, was measured:
+// each publication set off a storm of failed swaps on one address that stalled every other atomic of the kernel, 0.84 -> 3.4
+// ms per sweep).  Ring 1 holds what the low-priority chains publish while the machine is backed up; it is looked at only by
+// a workgroup that has just finished a task and finds ring 0 without a backlog, and claimed by compare-and-swap (few
+// contenders, never a waiter).  The end of the sweep comes as one poison per workgroup through ring 0.
+__device__ __noinline__ unsigned int ptq_take(const PtQueueArgs *qp, unsigned int fin_target, int *d_status)
+{
+    const PtQueueArgs q = *qp;
+    (void)fin_target;
+    unsigned int *tail0 = q.ctl, *head0 = q.ctl + 16, *tail1 = q.ctl + 32, *head1 = q.ctl + 48;
+    unsigned long long *slot = nullptr;
+    unsigned int want = 0;
+    // ring 1, if ring 0 has no backlog
+    if ((int)(__hip_atomic_load(tail0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+              __hip_atomic_load(head0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
+        unsigned int h = __hip_atomic_load(head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+        for (int tries = 0; tries < 64; ++tries) {
+            const unsigned int t = __hip_atomic_load(tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(t - h) <= 0)
+                break;
+            if (__hip_atomic_compare_exchange_strong(head1, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                slot = q.slots + (size_t)(q.qmask + 1u) + (h & q.qmask);  // (its slot is filled right after the reservation we saw)
+                want = h + 1u;
+                break;
+            }
+        }
+    }
+    if (!slot) {
+        const unsigned int t = __hip_atomic_fetch_add(head0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot = q.slots + (t & q.qmask);
+        want = t + 1u;
+    }
+    int polls = 0;
+#pragma unroll 1
+    for (;;) {
+        // relaxed polls (an acquire per poll would invalidate the caches under the workgroups that are computing)
+        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)(v >> 32) == want) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // hipcc: agent scope
+            return (unsigned int)v;
+        }
+        if (__hip_atomic_load(q.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            return RTMI_PTQ_POISON;
+        __builtin_amdgcn_s_sleep(8);
+        if (++polls > (1 << 23)) {  // seconds: never expected
+            __hip_atomic_store(q.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d_status)
+                atomicOr(d_status, 16);
+            return RTMI_PTQ_POISON;
+        }
+    }
+}
+
+// The chain's step(s) and what follows from them, by wave 0 of the calling workgroup (all 64 lanes call).  Real calls (this
+// one and ptq_take), with the queue's words read from memory: the kernel around them is the likelihood body at its register
+// limit, and everything that is inlined next to it is paid for in spills inside its loops.
+__device__ __noinline__ void ptq_step_and_publish(const rtmi_pt_dev::PtDev *dp, const PtQueueArgs *qp, int chain, int begin,
+                                                  int nwg, unsigned int fin_target, int *d_status)
+{
+    const PtQueueArgs q = *qp;
+    const int lane = threadIdx.x & 63;
+    // how the rings stand: tasks published and not yet claimed
+    int backlog = 0;
+#pragma unroll
+    for (int r = 0; r < RTMI_PTQ_RINGS; ++r)
+        backlog += (int)(__hip_atomic_load(q.ctl + 32 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                         __hip_atomic_load(q.ctl + 32 * r + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int task_src = backlog <= 0 ? q.task_fine : (backlog < nwg / 2 ? (q.task_fine + q.task_coarse) / 2 : q.task_coarse);
+    int fin_ = 0, nact_ = 0, guard = 0;
+#pragma unroll 1
+    for (;;) {
+        pt_step_spec_call(dp, chain, begin, -task_src);
+        __threadfence();                  // the rows are out before the tasks; and this workgroup (one L1) reads them afresh, too
+        __builtin_amdgcn_s_dcache_inv();  // ... the chain's words are wave-uniform: scalar loads
+        begin = 0;
+        fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin_ || nact_ > 0)
+            break;
+        if (++guard > 4 * RTMI_PT_MAX_K) {  // never expected: a chain that neither proposes nor finishes
+            if (lane == 0 && d_status)
+                atomicOr(d_status, 16);
+            fin_ = 1;  // count it as complete so that the launch ends
+            break;
+        }
+    }
+    const int D = q.nspec;
+    if (fin_) {
+        unsigned int done = 0;
+        if (lane == 0) {
+            __hip_atomic_store(q.rem + chain, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = __hip_atomic_fetch_add(q.nfinished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        }
+        done = (unsigned int)__builtin_amdgcn_readfirstlane((int)done);
+        if (done == fin_target) {
+            // the sweep is complete: one poison per workgroup of the launch, through the ticket ring
+            unsigned int base = 0;
+            if (lane == 0)
+                base = __hip_atomic_fetch_add(q.ctl, (unsigned int)nwg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            for (int i = lane; i < nwg; i += 64) {
+                const unsigned int t = base + (unsigned int)i;
+                __hip_atomic_store(q.slots + (t & q.qmask), ((unsigned long long)(t + 1u) << 32) | RTMI_PTQ_POISON, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // priority: slots this chain still has to decide against the most any chain has
+    const int k_ = __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cur_ = __hip_atomic_load(dp->cur + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int myrem = 2 * k_ - cur_ > 0 ? 2 * k_ - cur_ : 0;
+    if (lane == 0)
+        __hip_atomic_store(q.rem + chain, (unsigned int)myrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int gmax = myrem;
+    for (int c0 = 0; c0 < q.nchains; c0 += 64) {
+        const int c = c0 + lane;
+        const int r_ = c < q.nchains ? (int)__hip_atomic_load(q.rem + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        gmax = max(gmax, wave_max_i32(r_));
+    }
+    // ring 1 only for a chain that is not among the longest AND while ring 0 is backed up (without a backlog the idle
+    // workgroups are waiting on ring-0 tickets, and whatever is published goes to them)
+    const int backlog0 = (int)(__hip_atomic_load(q.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                               __hip_atomic_load(q.ctl + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int ring = (myrem + D >= gmax || backlog0 <= 0) ? 0 : 1;
+    // the window's tasks: row alist[a] in rowwg shares, a < nact (<= PT_SPEC_MAX rows)
+    int e_of[PT_SPEC_MAX], nw_of[PT_SPEC_MAX];
+    int ntask = 0;
+#pragma unroll
+    for (int a_ = 0; a_ < PT_SPEC_MAX; ++a_) {
+        e_of[a_] = 0;
+        nw_of[a_] = 0;
+        if (a_ < nact_) {
+            e_of[a_] = dp->alist[chain * D + a_];
+            nw_of[a_] = dp->rowwg[chain * D + e_of[a_]];
+            ntask += nw_of[a_];
+        }
+    }
+    unsigned int base = 0;
+    if (lane == 0) {
+        __hip_atomic_store(q.pendcnt + chain, (unsigned int)ntask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = __hip_atomic_fetch_add(q.ctl + 32 * ring, (unsigned int)ntask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    unsigned long long *slots = q.slots + (size_t)ring * (q.qmask + 1u);
+    for (int i = lane; i < ntask; i += 64) {
+        int r = i, a_sel = 0;
+#pragma unroll
+        for (int a_ = 0; a_ < PT_SPEC_MAX - 1; ++a_)
+            if (a_sel == a_ && r >= nw_of[a_]) {
+                r -= nw_of[a_];
+                a_sel = a_ + 1;
+            }
+        int e_sel = 0, nw_sel = 1;
+#pragma unroll
+        for (int a_ = 0; a_ < PT_SPEC_MAX; ++a_)
+            if (a_ == a_sel) {
+                e_sel = e_of[a_];
+                nw_sel = nw_of[a_];
+            }
+        const unsigned int t = base + (unsigned int)i;
+        __hip_atomic_store(slots + (t & q.qmask), ((unsigned long long)(t + 1u) << 32) | RTMI_PTQ_WORD(chain, e_sel, r, nw_sel),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int TF>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_queue_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, const PtQueueArgs *qp,
+                                                                              unsigned int fin_target, int lds_ctl)
 {
     using namespace rtmi_pt_dev;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     int *const d_status = a.d_status;
-    volatile int *ctl = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_raw) + w.lds_ctl);  // past the likelihood's LDS: [0] go on, [1] done
-    const int gx = w.gx;
-    int chain, row;
-    if (w.xcd_map) {
-        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        chain = xcd * (w.nchains >> 3) + loc / gx;
-        row = loc % gx;
-    } else {
-        chain = blockIdx.x / gx;
-        row = blockIdx.x % gx;
+    // past the likelihood's LDS: [0] task word, [1] take the chain's step; then (diagnostic, thread 0 only) 64-bit sums of
+    // ticks in tasks / steps / waits and counts of tasks / steps
+    volatile unsigned int *ctl = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(lds_raw) + lds_ctl);
+    volatile unsigned long long *dg = reinterpret_cast<volatile unsigned long long *>(reinterpret_cast<char *>(lds_raw) + lds_ctl + 16);
+    const bool diag = qp->stats != nullptr;  // wave-uniform
+    const int nwg = gridDim.x;
+    if (diag && threadIdx.x == 0) {
+        dg[0] = dg[1] = dg[2] = dg[3] = dg[4] = 0ull;
+        dg[5] = __builtin_amdgcn_s_memrealtime();
     }
-    volatile unsigned int *flag = w.flag + chain, *count = w.count + chain, *abort_word = w.abort_;
-    const unsigned int count_base = __hip_atomic_load((unsigned int *)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int D = w.nspec;
-    const int max_pass = 2 * w.nslots_k + 2;  // a pass retires at least one slot of the chain
+    // the first step of every chain
+    if (threadIdx.x < 64) {
+        const int nchains = qp->nchains;
 #pragma unroll 1
-    for (int pass = 0; pass <= max_pass; ++pass) {
-        const unsigned int target = w.epoch + (unsigned int)pass + 1u;
-        if (row == 0) {
-            if (threadIdx.x < 64) {
-                int begin = pass == 0 ? 1 : 0, guard = 0;
-                // steps without a likelihood pass in between: windows whose proposals affect no source
-#pragma unroll 1
-                for (;;) {
-                    pt_step_spec_call(dp, chain, begin, gx);
-                    __threadfence();  // the rows are out before the flag; and this workgroup (one L1) reads them afresh, too
-                    __builtin_amdgcn_s_dcache_inv();  // ... and so does a step that follows at once (the chain's words are wave-uniform: scalar loads)
-                    begin = 0;
-                    const int fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (fin_ || nact_ > 0 || ++guard > 4 * RTMI_PT_MAX_K)
-                        break;
-                }
+        for (int c = blockIdx.x; c < nchains; c += nwg) {
+            const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            ptq_step_and_publish(dp, qp, c, 1, nwg, fin_target, d_status);
+            if (diag && threadIdx.x == 0) {
+                dg[1] += __builtin_amdgcn_s_memrealtime() - t0;
+                dg[4] += 1ull;
             }
-            __builtin_amdgcn_s_dcache_inv();
-            __syncthreads();
-            if (threadIdx.x == 0)
-                __hip_atomic_store((unsigned int *)flag, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (threadIdx.x == 0)
-                ctl[0] = pt_wait_reached(flag, target, abort_word, d_status) ? 1 : 0;
-            __syncthreads();
-            if (!ctl[0])
-                return;
-            __builtin_amdgcn_s_dcache_inv();
         }
-        // the chain's state after the step (written before the flag, read after it)
-        const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int nact = __builtin_amdgcn_readfirstlane(__hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (fin || nact <= 0) {
-            if (!fin && threadIdx.x == 0 && d_status)
-                atomicOr(d_status, 16);  // never expected: the leading workgroup's guard ran out
-            return;  // the sweep of this chain is complete
+    }
+#pragma unroll 1
+    for (;;) {
+        __syncthreads();  // (ctl is free; LDS of the task before is free)
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            ctl[0] = ptq_take(qp, fin_target, d_status);
+            if (diag) {
+                const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+                dg[2] += t1 - t0;
+                dg[6] = t1;  // the task starts
+            }
         }
-        {
-            const int ai = row % nact, sub = row / nact, nw = (gx - ai + nact - 1) / nact;
-            const int e = __builtin_amdgcn_readfirstlane(dp->alist[chain * D + ai]);
-            fused_body<double, false, false, true, false, TF, INCR, true>(a, chain * D + e, sub, nw, reinterpret_cast<double *>(lds_raw));
+        __syncthreads();
+        const unsigned int word = ctl[0];
+        if (word & RTMI_PTQ_POISON) {
+            if (diag && threadIdx.x == 0) {
+                unsigned long long *st = qp->stats;
+                __hip_atomic_fetch_add(st + 0, dg[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 1, dg[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 2, dg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 3, dg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 4, dg[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 5, __builtin_amdgcn_s_memrealtime() - dg[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
-        __syncthreads();  // the workgroup's residual sum is written (thread 0), LDS is free again
+        __builtin_amdgcn_s_dcache_inv();
+        const int chain = (int)(word & 0xFFFFu), e = (int)((word >> 16) & 7u), sub = (int)((word >> 19) & 63u), nw = (int)((word >> 25) & 63u) + 1;
+        fused_body<double, false, false, true, false, TF, true, true>(a, chain * qp->nspec + e, sub, nw, reinterpret_cast<double *>(lds_raw));
+        __syncthreads();  // the task's sum is written (thread 0), LDS is free again
         if (threadIdx.x == 0) {
             __threadfence();
-            __hip_atomic_fetch_add((unsigned int *)count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (row == 0)
-                ctl[0] = pt_wait_reached(count, count_base + (unsigned int)(pass + 1) * (unsigned int)gx, abort_word, d_status) ? 1 : 0;
+            const unsigned int before = __hip_atomic_fetch_sub(qp->pendcnt + chain, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            ctl[1] = before == 1u ? 1u : 0u;
+            if (before == 1u)
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (diag) {
+                dg[0] += __builtin_amdgcn_s_memrealtime() - dg[6];
+                dg[3] += 1ull;
+            }
         }
-        if (row == 0) {
-            __syncthreads();
-            if (!ctl[0])
-                return;
+        __syncthreads();
+        if (ctl[1]) {  // this was the last task of the chain's window: its step is ours
             __builtin_amdgcn_s_dcache_inv();
+            if (threadIdx.x < 64) {
+                const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                ptq_step_and_publish(dp, qp, chain, 0, nwg, fin_target, d_status);
+                if (diag && threadIdx.x == 0) {
+                    dg[1] += __builtin_amdgcn_s_memrealtime() - t0;
+                    dg[4] += 1ull;
+                }
+            }
         }
     }
-    // never expected: a chain that is not complete after 2 k + 2 passes
-    if (threadIdx.x == 0 && d_status)
-        atomicOr(d_status, 16);
 }
 
 template <int TF, bool INCR>
@@ -1623,6 +1840,20 @@ extern "C" hipError_t rtmi_launch_fastmath_values_f32(const float *d_w, const fl
 // ---------------------------------------------------------------------------------------------
 // Launchers (host).  No allocation, no synchronisation: graph-capturable.
 // ---------------------------------------------------------------------------------------------
+// The name of the kernel the calling thread's last launcher call dispatched, spelled as rocprofv3 prints it: what bench.py
+// reports as `roofline.kernel`, so that the line can be matched against a kernel trace by name (rtmi_last_kernel_name).
+static thread_local char g_last_kernel[192] = "";
+static void note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+static void note_kernel(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof g_last_kernel, fmt, ap);
+    va_end(ap);
+}
+static const char *tf(bool b) { return b ? "true" : "false"; }
+extern "C" const char *rtmi_last_kernel_name(void) { return g_last_kernel; }
+
 extern "C" int rtmi_launch_grid_x(int64_t nsrc, int nmodels, int num_cus)
 {
     const int64_t ntiles = (nsrc + RTMI_BLOCK - 1) / RTMI_BLOCK;
@@ -1652,6 +1883,10 @@ static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &args, int nmodels, i
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
     const bool want_ss = a.d_obs != nullptr;
+    {
+        const char *tn = std::is_same<T, double>::value ? "double" : "float";
+        note_kernel("void rtmi::trace_kernel<%s, %s, %s, %s>(rtmi::TraceArgsT<%s>)", tn, tf(want_p && !want_ss), tf(want_t || !want_ss), tf(want_ss), tn);
+    }
     if (want_ss && want_t)
         hipLaunchKernelGGL((trace_kernel<T, false, true, true>), grid, block, lds_bytes, stream, a);
     else if (want_ss)
@@ -1812,8 +2047,11 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
     const bool want_p = a.d_p_final != nullptr;
     const bool want_t = a.d_timeP != nullptr;
     const bool want_ss = a.d_obs != nullptr;
+    const char *tname = std::is_same<T, double>::value ? "double" : "float";
 #define RTMI_LAUNCH_FUSED(P, WT, S, DG)                                                                          \
     do {                                                                                                        \
+        note_kernel("void rtmi::fused_kernel<%s, %s, %s, %s, %s, %d, false>(rtmi::FusedArgsT<%s>)", tname, tf(P), tf(WT), tf(S), \
+                    tf(DG), a.rows, tname);                                                                     \
         if (a.rows == 1)                                                                                        \
             hipLaunchKernelGGL((fused_kernel<T, P, WT, S, DG, 1>), grid, block, lds_bytes, stream, a);          \
         else if (a.rows == 2)                                                                                   \
@@ -1825,6 +2063,7 @@ static hipError_t launch_fused_t(const rtmi::FusedArgsT<T> &args, int nmodels, i
         RTMI_LAUNCH_FUSED(false, true, true, false);
     else if (want_ss && a.d_partial_x && std::is_same<T, double>::value) {
         // the tempering sampler's form of the likelihood (exact sums, optionally incremental: PtInc): its own instantiation
+        note_kernel("void rtmi::fused_kernel<%s, false, false, true, false, %d, true>(rtmi::FusedArgsT<%s>)", tname, a.rows, tname);
         if (a.rows == 1)
             hipLaunchKernelGGL((fused_kernel<T, false, false, true, false, 1, true>), grid, block, lds_bytes, stream, a);
         else if (a.rows == 2)
@@ -1871,19 +2110,8 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
     size_t lds_bytes = 0;
     int threads = 0;
-    int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
-                                 &a.slots, &lds_bytes);
-    if (ws.nspec > 0 && gx >= 1) {
-        // speculative step: a row is evaluated by as few as floor(gx / nspec) of the chain's workgroups -- the record area is
-        // sized for that share (a larger share would take several rounds of it)
-        const int nw_min = gx / ws.nspec > 0 ? gx / ws.nspec : 1;
-        int threads2 = 0;
-        const int g2 = rtmi_fused_geometry(a.nsrc, max_nlayers, (nchains * gx + nw_min - 1) / nw_min, num_cus, waves_per_simd,
-                                           (int)sizeof(double), &threads2, &a.slots, &lds_bytes);
-        (void)g2;
-        if (threads2 > threads)
-            threads = threads2;
-    }
+    const int gx = rtmi_fused_geometry(a.nsrc, max_nlayers, nchains, num_cus, waves_per_simd, (int)sizeof(double), &threads,
+                                       &a.slots, &lds_bytes);
     static const bool verbose = getenv("RTMI_PT_VERBOSE") != nullptr;  // read once
     ws.lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
     lds_bytes = (size_t)ws.lds_ctl + 16;
@@ -1901,10 +2129,9 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
         a.rows = 0;
     const void *fns[2][2] = {{reinterpret_cast<const void *>(&pt_sweep_kernel<0, false>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, false>)},
                              {reinterpret_cast<const void *>(&pt_sweep_kernel<0, true>), reinterpret_cast<const void *>(&pt_sweep_kernel<1, true>)}};
-    const void *fns_spec[2] = {reinterpret_cast<const void *>(&pt_sweep_spec_kernel<0, true>), reinterpret_cast<const void *>(&pt_sweep_spec_kernel<1, true>)};
-    if (ws.nspec > 0 && !a.d_partial_x)
-        return hipErrorInvalidValue;  // (the speculative step needs the exact sums)
-    const void *fn = ws.nspec > 0 ? fns_spec[a.rows] : fns[a.d_partial_x ? 1 : 0][a.rows];
+    if (ws.nspec > 0)
+        return hipErrorInvalidValue;  // (the speculative step runs over the task queue: rtmi_launch_pt_queue)
+    const void *fn = fns[a.d_partial_x ? 1 : 0][a.rows];
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)
         return e;
@@ -1919,6 +2146,50 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
                         "workgroups per CU %d\n", gx * nchains, threads, lds_bytes, hipGetErrorString(e), coop, per_cu);
     }
     return e;
+}
+
+extern "C" hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
+                                           const rtmi::PtQueueArgs *d_q, int nspec, unsigned int fin_target, int max_nlayers,
+                                           int num_cus, int waves_per_simd, int task_src, hipStream_t stream)
+{
+    using namespace rtmi;
+    using rtmi_pt_dev::PtDev;
+    if (!args || !ptdev || !d_q || ptdev_bytes != sizeof(PtDev) || !args->d_obs || !args->d_nlayers || args->d_timeP ||
+        !args->d_partial_x || nspec < 1 || nspec > PT_SPEC_MAX || task_src < 64)
+        return hipErrorInvalidValue;
+    {
+        const hipError_t e = prepare_fused_t<double>();
+        if (e != hipSuccess)
+            return e;
+    }
+    FusedArgs a = *args;
+    const PtDev *dp = static_cast<const PtDev *>(ptdev);  // a DEVICE copy of the handle's view
+    a.max_nlayers = max_nlayers;
+    a.rows = RTMI_TABLE_FORM(max_nlayers);
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
+    a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
+    // one workgroup per CU; its record area holds one task (task_src sources + a chunk of rounding) in one round
+    size_t lds_bytes = 0;
+    int threads = 0;
+    const int64_t task = ((int64_t)task_src + 63) / 64 * 64 + 64;
+    (void)rtmi_fused_geometry(task < a.nsrc ? task : a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads,
+                              &a.slots, &lds_bytes);
+    const int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
+    lds_bytes = (size_t)lds_ctl + 16 + 64;  // + the kernel's control words and its diagnostic sums
+    if (lds_bytes > 160 * 1024 || threads < 64)
+        return hipErrorInvalidValue;
+    if (a.rows == 2)
+        a.rows = 0;  // (as in rtmi_launch_pt_sweep: form 0 with the body inlined into a loop)
+    const void *fn = a.rows == 1 ? reinterpret_cast<const void *>(&pt_sweep_queue_kernel<1>) : reinterpret_cast<const void *>(&pt_sweep_queue_kernel<0>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)
+        return e;
+    if (a.rows == 1)
+        hipLaunchKernelGGL((pt_sweep_queue_kernel<1>), dim3((unsigned)num_cus), dim3((unsigned)threads), lds_bytes, stream, a, dp, d_q, fin_target, lds_ctl);
+    else
+        hipLaunchKernelGGL((pt_sweep_queue_kernel<0>), dim3((unsigned)num_cus), dim3((unsigned)threads), lds_bytes, stream, a, dp, d_q,
+                           fin_target, lds_ctl);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers,

@@ -109,15 +109,18 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
         d.nact[c] = 1;
         d.alist[m] = 0;
         d.rowwg[m] = d.gx_launch;
-        o->pzthr = d.pend_z[3 * c + 0];
-        o->pdl1 = d.pend_z[3 * c + 1];
-        o->pdl2 = d.pend_z[3 * c + 2];
         o->pending = d.pend_i[4 * c + 0];
-        o->pend_row = d.pend_i[4 * c + 1];
-        o->pn0 = d.pend_i[4 * c + 2];
+        o->pend_idx = d.pend_i[4 * c + 1];
         o->mover = 1;
         o->cur_row = c;
         o->prop_row = d.nchains + (d.wbuf[c] * d.nchains + c) * d.nspec;
+        rtmi::PtPend *pp = d.pinfo + (size_t)(d.wbuf[c] * d.nchains + c) * d.nspec;  // (the evaluation is "accepted")
+        pp->zthr = -INFINITY;
+        pp->dl1 = pp->dl2 = 0.0;
+        pp->n0 = 0;
+        pp->prop_row = o->prop_row;
+        unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;
+        ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
     }
 }
 
@@ -247,6 +250,15 @@ struct rtmi_pt {
     int *d_spec_i32 = nullptr;       // cur | fin | nwin | wend | winv | nact | wbuf | pend_i[4] (per chain), pslot | pinv | rowwg | alist (per row)
     unsigned long long *d_spec_u64 = nullptr;  // wctr (per chain), pctr (per row)
     double *d_pend_z = nullptr;      // [nchains][3]
+    rtmi::PtPend *d_pinfo = nullptr; // [2][rows]
+    // the task queue of the speculative sweep (rtmi_kernels.hip::pt_sweep_queue_kernel)
+    unsigned long long *d_qslots = nullptr;
+    unsigned int *d_qctl = nullptr;  // tail | head | nfinished | abort (64-byte apart), then pendcnt[nchains]
+    unsigned int qmask = 0;
+    rtmi::PtQueueArgs *d_qargs = nullptr;  // device copy of the queue's constant words
+    unsigned long long *d_qstats = nullptr;  // RTMI_PT_QSTATS: where the workgroups' time went (printed by rtmi_pt_run)
+    unsigned int q_fin_target = 0;   // chains completed over all queue launches so far
+    int task_src = 0, task_fine = 0;
     std::vector<rtmi::PtInc> inc0;   // (one-at-a-time step) the rows of the residual slab never change: a chain's record as reset by rtmi_pt_set_chain
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -297,7 +309,8 @@ int launch_likelihood(rtmi_pt *h)
     const size_t n = (size_t)h->nsrc;
     int rc = launch_batch(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nrows, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                           nullptr, h->d_set + 2 * n, h->d_partial, true, h->cus, &gx, h->stream,
-                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride);
+                          h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride,
+                          h->spec ? 1 : 0, h->d_pinfo);
     if (rc)
         return rc;
     if (gx != h->gx_launch)
@@ -371,7 +384,24 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
                 (void)hipEventRecord(e, s);
         }
     };
-    if (engine == 1 && h->use_persistent && h->d_sync && h->d_ptdev && h->d_partial_x) {
+    if (engine == 1 && h->use_persistent && h->spec && h->d_qslots && h->d_ptdev && h->d_partial_x) {
+        // the speculative sweep over the task queue: one ordinary launch of a workgroup per CU
+        if (ev0)
+            HIP_TRY(hipEventRecord(ev0, h->stream));
+        Closer closer{ev1, h->stream};
+        const size_t n = (size_t)h->nsrc;
+        if (launch_pt_queue(h->d.V, h->d.D, h->d.NL, h->ld_model, h->max_nl, h->d_set, h->d_set + n, h->nsrc, h->d_set + 2 * n,
+                            h->cus, h->d_ptdev, sizeof h->d, h->d_qargs, h->nspec, h->q_fin_target + (unsigned int)h->nchains,
+                            h->task_src, h->stream, h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x,
+                            h->d.part_stride, h->d_pinfo) == RTMI_OK) {
+            h->q_fin_target += (unsigned int)h->nchains;
+            h->launches += 1;
+            return RTMI_OK;
+        }
+        h->use_persistent = false;
+        h->engine = 0;
+        closer.e = nullptr;
+    } else if (engine == 1 && h->use_persistent && !h->spec && h->d_sync && h->d_ptdev && h->d_partial_x) {
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
         Closer closer{ev1, h->stream};
@@ -385,12 +415,12 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         w.count = h->d_sync + h->nchains;
         w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
         const size_t n = (size_t)h->nsrc;
-        w.nspec = h->spec ? h->nspec : 0;
+        w.nspec = 0;
         if (launch_pt_sweep(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc,
                             h->d_set + 2 * n, h->d_partial, h->cus, h->d_ptdev, sizeof h->d, &w, h->stream,
                             h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x,
                             h->d.part_stride) == RTMI_OK) {
-            h->epoch += h->spec ? 4096u : 2u * (unsigned int)ks;  // (spec: passes of a sweep are counted from a tag of its own)
+            h->epoch += 2u * (unsigned int)ks;
             h->launches += 1;
             return RTMI_OK;
         }
@@ -530,7 +560,19 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n, nr = (size_t)h->nrows;
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);     // workgroups per CHAIN (persistent engine)
     h->gx_launch = batch_grid_x(h->nrows, h->max_nl, c.set_n, c.cus);    // workgroups per ROW of the batched launch
-    const int pstride = gx > h->gx_launch ? gx : h->gx_launch;
+    // queue engine: a row is evaluated as tasks of about task_src loaded sources (RTMI_PT_TASK_SRC; 2560 = 2.5 records per
+    // lane of a 1024-thread workgroup: enough to keep the lanes refilled, little enough for one round of the record area)
+    h->task_src = 2560;   // RTMI_PT_TASK_SRC: while the rings are backed up (the record area of a task is sized for this)
+    h->task_fine = 1024;  // RTMI_PT_TASK_FINE: while workgroups are idle
+    if (const char *e = getenv("RTMI_PT_TASK_SRC"))
+        h->task_src = atoi(e) >= 64 ? atoi(e) : h->task_src;
+    if (const char *e = getenv("RTMI_PT_TASK_FINE"))
+        h->task_fine = atoi(e) >= 64 ? atoi(e) : h->task_fine;
+    if (h->task_fine > h->task_src)
+        h->task_fine = h->task_src;
+    int nw_max = (int)((c.set_n + h->task_fine - 1) / h->task_fine);
+    nw_max = nw_max < 1 ? 1 : (nw_max > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw_max);
+    const int pstride = gx > h->gx_launch ? gx : h->gx_launch;  // (with the speculative step a row's sums are ONE accumulator)
     const size_t nf64 = 2 * nc * K + 2 * nr * K + 4 * nc + nr + 2 * nr * ldm;
     const size_t ni32 = nc + 3 * nr;
     const size_t nsi32 = 11 * nc + 4 * nr, nsu64 = nc + nr;
@@ -548,7 +590,9 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_spec_i32, nsi32 * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_spec_u64, nsu64 * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&h->d_pend_z, 3 * nc * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&h->d_pinfo, 2 * nr * sizeof(rtmi::PtPend)) == hipSuccess &&
               hipMalloc((void **)&h->d_cdf, (size_t)ncdf * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_qctl, (32 * RTMI_PTQ_RINGS + 32 + 2 * nc) * sizeof(unsigned int)) == hipSuccess &&
               (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nr * (size_t)pstride * sizeof(unsigned long long)) == hipSuccess);
     // The residual cache of the incremental likelihood (the chains' current residuals + one row per model row, twice with the
     // speculative step: the two sets alternate) and its counters exist only where they are read: the incremental likelihood
@@ -570,6 +614,41 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     } else {
         h->incremental = false;
     }
+    if (ok && h->spec) {
+        // the ring holds every task that can be out at once (every row of every chain in nw_max shares) + one poison per workgroup
+        size_t need = 2 * (nr * (size_t)nw_max + (size_t)c.cus + 64);
+        size_t cap = 1024;
+        while (cap < need)
+            cap *= 2;
+        h->qmask = (unsigned int)(cap - 1);
+        ok = hipMalloc((void **)&h->d_qslots, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemsetAsync(h->d_qslots, 0, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long), h->stream) == hipSuccess;
+    }
+    const size_t nqctl = 32 * RTMI_PTQ_RINGS + 32 + 2 * nc;
+    if (ok)
+        ok = hipMemsetAsync(h->d_qctl, 0, nqctl * sizeof(unsigned int), h->stream) == hipSuccess;
+    if (ok && h->spec) {
+        rtmi::PtQueueArgs q;
+        memset(&q, 0, sizeof q);
+        q.slots = h->d_qslots;
+        q.ctl = h->d_qctl;                               // per ring: tail, head (cache lines of their own)
+        q.nfinished = h->d_qctl + 32 * RTMI_PTQ_RINGS;
+        q.abort_ = h->d_qctl + 32 * RTMI_PTQ_RINGS + 16;
+        q.pendcnt = h->d_qctl + 32 * RTMI_PTQ_RINGS + 32;
+        q.rem = q.pendcnt + nc;
+        q.qmask = h->qmask;
+        q.nchains = h->nchains;
+        q.nspec = h->nspec;
+        q.task_fine = h->task_fine;
+        q.task_coarse = h->task_src;
+        if (getenv("RTMI_PT_QSTATS")) {
+            ok = hipMalloc((void **)&h->d_qstats, 8 * sizeof(unsigned long long)) == hipSuccess &&
+                 hipMemset(h->d_qstats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
+            q.stats = h->d_qstats;
+        }
+        ok = hipMalloc((void **)&h->d_qargs, sizeof q) == hipSuccess &&
+             hipMemcpy(h->d_qargs, &q, sizeof q, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_inc, 0, nr * sizeof(rtmi::PtInc), h->stream) == hipSuccess &&
@@ -577,6 +656,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
              hipMemsetAsync(h->d_spec_i32, 0, nsi32 * sizeof(int), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_spec_u64, 0, nsu64 * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_pend_z, 0, 3 * nc * sizeof(double), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_pinfo, 0, 2 * nr * sizeof(rtmi::PtPend), h->stream) == hipSuccess &&
              (!h->d_inc_counts || hipMemsetAsync(h->d_inc_counts, 0, 2 * nr * (size_t)pstride * sizeof(unsigned long long), h->stream) == hipSuccess) &&
              (!h->d_partial_x || hipMemsetAsync(h->d_partial_x, 0, 4 * nr * (size_t)pstride * sizeof(unsigned long long), h->stream) == hipSuccess) &&
              (!h->d_r2 || hipMemsetAsync(h->d_r2, 0, r2rows * n * sizeof(double), h->stream) == hipSuccess) &&
@@ -666,6 +746,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.spec_step = h->spec ? 1 : 0;
     d.part_stride = pstride;
     d.gx_launch = h->gx_launch;
+    d.task_src = h->task_src;
     if (ok) {
         double *f = h->d_f64;
         d.z = f, f += nc * K;
@@ -707,6 +788,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.wctr = h->d_spec_u64;
         d.pctr = h->d_spec_u64 + nc;
         d.pend_z = h->d_pend_z;
+        d.pinfo = h->d_pinfo;
+        d.acc = h->d_partial_x;
         // one-at-a-time step: a chain's rows of the residual slab never change (current residuals: row c; its proposal's: row
         // nchains + c); the speculative step writes them with every proposal
         h->inc0.assign(nc, rtmi::PtInc{});
@@ -751,7 +834,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
                     h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x,
-                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z};
+                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qslots, h->d_qctl, h->d_qargs, h->d_qstats};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -1133,6 +1216,16 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
         }
     }
     const int rc = finish(h);  // the one synchronisation of the call
+    if (!rc && h->d_qstats) {
+        unsigned long long st[8];
+        HIP_TRY(hipMemcpy(st, h->d_qstats, sizeof st, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(h->d_qstats, 0, sizeof st));
+        if (st[5] > 0)
+            fprintf(stderr, "rtmi: queue sweeps (%d): %llu tasks (%.1f us each), %llu steps (%.1f us each); of the workgroups' time "
+                            "%.1f %% in tasks, %.1f %% in steps, %.1f %% waiting for a task\n", nsweeps, st[3],
+                    st[3] ? 0.01 * (double)st[0] / (double)st[3] : 0.0, st[4], st[4] ? 0.01 * (double)st[1] / (double)st[4] : 0.0,
+                    100.0 * (double)st[0] / (double)st[5], 100.0 * (double)st[1] / (double)st[5], 100.0 * (double)st[2] / (double)st[5]);
+    }
     return rc ? rc : refresh_kbound(h);
 }
 

@@ -68,10 +68,13 @@ struct PtDev {
     int *nact;            // [nchains] entries that go through the likelihood in this pass ...
     int *alist;           // [rows]   ... and which (alist[chain * nspec + a] = e of the a-th)
     int *wbuf;            // [nchains] which of the two sets of proposal rows (of the residual slab) the chain's rows write next
-    // chain-level record of the pending accepted proposal (copied into every row's PtInc)
-    double *pend_z;       // [nchains][3] pzthr, pdl1, pdl2
-    int *pend_i;          // [nchains][4] pending, pend_row, pn0, -
+    // chain-level record of the pending accepted proposal: pend_i[4 c] = pending, pend_i[4 c + 1] = its PtPend record + 1
+    double *pend_z;       // (unused)
+    int *pend_i;          // [nchains][4]
+    rtmi::PtPend *pinfo;  // [2][nchains * nspec] what a later pass needs to know about an accepted proposal (rtmi_kernels.h)
+    unsigned long long *acc;  // [rows][part_stride][4] = partial_x, writable: the step zeroes the accumulator of every row it proposes
     int gx_launch;        // per-slot engine: workgroups per row of the batched launch (rowwg of every evaluated row)
+    int task_src;         // queue engine: sources per task -- a row is evaluated as ceil(loaded sources / task_src) tasks
 };
 
 // Sources [0, prefix_above(d, z)) of the handle's depth-sorted set have depths < z: one load from the depth histogram (a
@@ -429,8 +432,9 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // row is read and written in the same pass, and exactly one row of a pass (the first that is evaluated) moves the pending
 // residuals to r2cur.
 // begin: first step of a sweep.  eval: decide an evaluation of the current state (rtmi_pt_evaluate) and propose nothing.
-// wg_total: workgroups the chain's rows share in the next pass (persistent engine; they are dealt to the evaluated rows
-// round-robin), 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows).
+// wg_total: > 0 workgroups the chain's rows share in the next pass (they are dealt to the evaluated rows round-robin),
+// 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows), < 0 = queue engine: a row is
+// cut into tasks of about -wg_total loaded sources.
 #define PT_SPEC_MAX 4  // (the window's records are held in registers; the step shares the sweep kernel's 128)
 
 template <int G>
@@ -460,11 +464,12 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     const int wend = d.wend[c], winv = d.winv[c];
     const unsigned long long wctr = d.wctr[c];
     int wbuf = d.wbuf[c];
-    int pending = d.pend_i[4 * c + 0], pend_row = d.pend_i[4 * c + 1], pn0 = d.pend_i[4 * c + 2];
-    double pzthr = d.pend_z[3 * c + 0], pdl1 = d.pend_z[3 * c + 1], pdl2 = d.pend_z[3 * c + 2];
-    int e_act[PT_SPEC_MAX], e_pk[PT_SPEC_MAX], e_slot[PT_SPEC_MAX], e_inv[PT_SPEC_MAX], e_wg[PT_SPEC_MAX];
-    unsigned long long e_ctr[PT_SPEC_MAX];
-    double e_lp[PT_SPEC_MAX];
+    int pending = d.pend_i[4 * c + 0], pend_idx = d.pend_i[4 * c + 1];
+    // everything the decisions need, in ONE round trip: the entries' records, their exact sums (the row's accumulator:
+    // three limbs + flags, added up by the row's workgroups with 64-bit atomics) and this lane's node of every entry
+    int e_act[PT_SPEC_MAX], e_pk[PT_SPEC_MAX], e_slot[PT_SPEC_MAX], e_inv[PT_SPEC_MAX];
+    unsigned long long e_ctr[PT_SPEC_MAX], e_a0[PT_SPEC_MAX], e_a1[PT_SPEC_MAX], e_a2[PT_SPEC_MAX], e_a3[PT_SPEC_MAX];
+    double e_lp[PT_SPEC_MAX], e_pz[PT_SPEC_MAX], e_pv[PT_SPEC_MAX];
 #pragma unroll
     for (int e = 0; e < PT_SPEC_MAX; ++e) {
         const bool on = e < D && e < nwin;
@@ -473,26 +478,24 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         e_pk[e] = on ? d.pk[m] : 0;
         e_slot[e] = on ? d.pslot[m] : 0;
         e_inv[e] = on ? d.pinv[m] : 0;
-        e_wg[e] = on ? d.rowwg[m] : 0;
         e_ctr[e] = on ? d.pctr[m] : 0ull;
         e_lp[e] = on ? d.plp[m] : 0.0;
+        e_pz[e] = on ? d.pz[(size_t)m * K + ic_] : 0.0;
+        e_pv[e] = on ? d.pv[(size_t)m * K + ic_] : 0.0;
+        const unsigned long long *w = d.partial_x + 4 * (size_t)m * d.part_stride;
+        e_a0[e] = on ? w[0] : 0ull;
+        e_a1[e] = on ? w[1] : 0ull;
+        e_a2[e] = on ? w[2] : 0ull;
+        e_a3[e] = on ? w[3] : 0ull;
     }
-    // SUM(DresRT**2) of every evaluated entry: its workgroups' exact sums (any order gives the same words)
+    // SUM(DresRT**2) of every evaluated entry
     double e_part[PT_SPEC_MAX];
 #pragma unroll
     for (int e = 0; e < PT_SPEC_MAX; ++e) {
-        e_part[e] = 0.0;
-        if (e < D && (e_act[e] == 1 || e_act[e] == 2)) {
-            rtmi::Acc192 tot = rtmi::acc_zero();
-            for (int j = 0; j < e_wg[e]; ++j) {
-                const unsigned long long *w = d.partial_x + 4 * ((size_t)(m0 + e) * d.part_stride + j);
-                rtmi::Acc192 o;
-                o.w0 = w[0];
-                o.w1 = w[1];
-                rtmi::acc_add(tot, o);
-            }
-            e_part[e] = rtmi::acc_to_double(tot);
-        }
+        rtmi::Acc192 tot;
+        tot.w0 = e_a0[e] + (e_a1[e] << 48);
+        tot.w1 = ((e_a1[e] >> 16) + (e_a2[e] << 32) + (tot.w0 < e_a0[e] ? 1ull : 0ull)) | (e_a3[e] & RTMI_ACC_FLAGS);
+        e_part[e] = rtmi::acc_to_double(tot);
     }
     long long *st = d.stats + (size_t)c * 8;
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr);
@@ -560,15 +563,18 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
             pending = 0;
         if (taken) {
             int a_act = 0;
+            double a_pz = 0.0, a_pv = 0.0;
 #pragma unroll
             for (int e = 0; e < PT_SPEC_MAX; ++e)
-                if (e == e_acc)
+                if (e == e_acc) {
                     a_act = e_act[e];
-            const int m = m0 + e_acc;
-            if (a_act != 2) {  // the proposal becomes the state (one more round trip, for the entry that was taken only)
+                    a_pz = e_pz[e];
+                    a_pv = e_pv[e];
+                }
+            if (a_act != 2) {  // the proposal becomes the state
                 if (i < k) {
-                    zi = d.pz[(size_t)m * K + ic_];
-                    vi = d.pv[(size_t)m * K + ic_];
+                    zi = a_pz;
+                    vi = a_pv;
                     d.z[row] = zi;
                     d.v[row] = vi;
                 }
@@ -576,15 +582,10 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                     d.k[c] = k;
             }
             if (a_act != 3) {
-                const rtmi::PtInc *o = d.inc + m;
                 pending = 1;
-                pzthr = o->zthr;
-                pdl1 = o->dl1;
-                pdl2 = o->dl2;
-                pn0 = o->n0;
-                pend_row = o->prop_row;
+                pend_idx = (wbuf * d.nchains + c) * D + e_acc + 1;  // its record was written when it was proposed
                 wbuf ^= 1;
-                if (pzthr == -INFINITY && !cache_ok) {
+                if (!cache_ok) {  // (without a valid cache every proposal is evaluated in full: this one was)
                     cache_ok = 1;
                     if (lead)
                         d.cache_valid[c] = 1;
@@ -627,11 +628,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         d.fin[c] = fin;
         d.wbuf[c] = wbuf;
         d.pend_i[4 * c + 0] = pending;
-        d.pend_i[4 * c + 1] = pend_row;
-        d.pend_i[4 * c + 2] = pn0;
-        d.pend_z[3 * c + 0] = pzthr;
-        d.pend_z[3 * c + 1] = pdl1;
-        d.pend_z[3 * c + 2] = pdl2;
+        d.pend_i[4 * c + 1] = pend_idx;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (d_st[j])
@@ -660,7 +657,8 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     int e = 0, s = cur, nact = 0;
     int inv = 0;                 // proposals outside the prior since the last entry
     int my_e = -1;               // lane a: the a-th evaluated entry of the window ...
-    double my_zeff = -INFINITY;  // ... and the depth above which no source is affected by it
+    int my_n0 = 0;               // ... and the prefix of the sorted sources that lies above everything it changes (one load from
+                                 // the depth histogram, issued as soon as the entry is known: it is waited for after the loop)
     unsigned long long idx = ctr;
     bool going = !eval && !fin && s < 2 * k;
     while (__any(going)) {
@@ -791,7 +789,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 }
                 if (!trivial && i == nact) {
                     my_e = e;
-                    my_zeff = fmin(zthr, fmin(dl_cur, dl_new));
+                    my_n0 = prefix_above(d, fmin(zthr, fmin(dl_cur, dl_new)));
                 }
                 if (lead) {
                     d.pk[m] = qk;
@@ -802,19 +800,23 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                     d.pctr[m] = rng.index;
                     d.NL[m] = trivial ? 0 : nl;  // (trivial: an inactive row -- nothing to evaluate)
                     if (!trivial) {
+                        const int prow = d.nchains + (wbuf * d.nchains + c) * D + e;
                         rtmi::PtInc *o = d.inc + m;
                         o->zthr = zthr;
                         o->dl1 = dl_cur;
                         o->dl2 = dl_new;
-                        o->pzthr = pzthr;
-                        o->pdl1 = pdl1;
-                        o->pdl2 = pdl2;
                         o->pending = pending;
-                        o->pn0 = pn0;
+                        o->pend_idx = pend_idx;
                         o->mover = nact == 0 ? 1 : 0;
                         o->cur_row = c;
-                        o->pend_row = pend_row;
-                        o->prop_row = d.nchains + (wbuf * d.nchains + c) * D + e;
+                        o->prop_row = prow;
+                        rtmi::PtPend *pp = d.pinfo + (size_t)(wbuf * d.nchains + c) * D + e;  // should it be accepted
+                        pp->zthr = zthr;
+                        pp->dl1 = dl_cur;
+                        pp->dl2 = dl_new;
+                        pp->prop_row = prow;
+                        unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;   // the row's sums start from zero
+                        ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
                         d.alist[m0 + nact] = e;
                     }
                 }
@@ -840,8 +842,19 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         if (eval)
             ;  // (the rows of an evaluation were written by pt_pack_current_kernel)
         else if (i < nact) {
-            d.rowwg[m0 + my_e] = wg_total > 0 ? (wg_total - i + nact - 1) / nact : d.gx_launch;
-            d.inc[m0 + my_e].n0 = prefix_above(d, my_zeff);
+            const int n0 = my_n0;
+            int nw = d.gx_launch;                        // per-slot engine: every row has the batched launch's workgroups
+            if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its evaluated rows
+                nw = (wg_total - i + nact - 1) / nact;
+                nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
+            } else if (wg_total < 0) {                   // queue engine: tasks of about -wg_total loaded sources
+                const long long loaded = (long long)d.nsrc - (d.incremental ? n0 : 0), T = -(long long)wg_total;
+                nw = (int)((loaded + T - 1) / T);
+                nw = nw < 1 ? 1 : (nw > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw);
+            }
+            d.rowwg[m0 + my_e] = nw;
+            d.inc[m0 + my_e].n0 = n0;
+            d.pinfo[(size_t)(wbuf * d.nchains + c) * D + my_e].n0 = n0;
         }
     }
     if (lead && !eval) {

@@ -69,6 +69,9 @@ SIGNATURES = {
     "rtmi_comm_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "rtmi_comm_destroy": (None, [_vp]),
     "rtmi_comm_size": (ctypes.c_int, [_vp]),
+    "rtmi_comm_rccl_version": (ctypes.c_int, []),
+    "rtmi_comm_rccl_library": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "rtmi_last_kernel_name": (ctypes.c_char_p, []),
     "rtmi_comm_rank": (ctypes.c_int, [_vp]),
     "rtmi_comm_allgather_f64": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
     "rtmi_init": (ctypes.c_int, [ctypes.c_int]),
@@ -167,8 +170,8 @@ def _host_call(symbol, vels, depths, NLayers, src_offset, src_depth, NSrc, timeP
     if keep_delta is not None:
         kd = ctypes.c_int(int(keep_delta))
         args.append(ctypes.byref(kd))
-    # a device failure inside the void drop-in symbols aborts the process by design; ask for the
-    # NaN-fill instead so that Python can raise
+    # a device failure inside the void drop-in symbols NaN-fills the output (and aborts only with RTMI_ABORT_ON_ERROR=1):
+    # make sure of the NaN-fill here so that Python can raise
     old = os.environ.get("RTMI_ABORT_ON_ERROR")
     os.environ["RTMI_ABORT_ON_ERROR"] = "0"
     try:
@@ -265,10 +268,31 @@ class Comm:
             raise RtmiError("rtmi_comm_create failed: " + self.lib.rtmi_last_error().decode("utf-8", "replace"))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def size(self) -> int:
+        """Ranks of the communicator as the library reports it (rtmi_comm_size)."""
+        return int(self.lib.rtmi_comm_size(self.h))
+
     def close(self):
         if self.h:
             self.lib.rtmi_comm_destroy(self.h)
             self.h = None
+
+
+def comm_rccl_version() -> int:
+    """ncclGetVersion of the RCCL librtmi.so's communicator binds to."""
+    return int(load_library().rtmi_comm_rccl_version())
+
+
+def comm_rccl_library() -> str:
+    """Path of the shared object ncclAllGather resolves to inside librtmi.so."""
+    buf = ctypes.create_string_buffer(1024)
+    _check(load_library().rtmi_comm_rccl_library(buf, 1024))
+    return buf.value.decode("utf-8", "replace")
+
+
+def last_kernel_name() -> str:
+    """Name (as rocprofv3 prints it) of the kernel this thread's last trace / batch launch dispatched."""
+    return load_library().rtmi_last_kernel_name().decode("utf-8", "replace")
 
 
 def swap_decide(logl_all, level, beta_of_level, seed: int, round_: int):

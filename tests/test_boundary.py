@@ -70,14 +70,19 @@ def test_fails_loudly_without_gpu(built):
     import raytracerfortran_amd as r
     with pytest.raises(r.RtmiError, match="no HIP device|failed"):
         r.dff([3000.0, 4000.0], [1000.0], 1, [100.0], [2000.0], 1)
-    # and the void drop-in symbol itself aborts the process (no silent garbage) unless told otherwise
+    # and the void drop-in symbol itself: the reason on stderr and NaN in every output (no silent garbage; an R session that
+    # loaded the library survives), or a hard stop with RTMI_ABORT_ON_ERROR=1
     code = ("import ctypes,numpy as np;from raytracerfortran_amd import raymod as m;"
-            "r=m.load_library();import os;os.environ.pop('RTMI_ABORT_ON_ERROR',None);"
+            "r=m.load_library();"
             "a=np.array([3000.,4000.]);d=np.array([1000.]);o=np.array([1.]);z=np.array([2000.]);t=np.zeros(1);"
             "n=ctypes.c_int(1);dp=ctypes.POINTER(ctypes.c_double);"
             "r.dff_(a.ctypes.data_as(dp),d.ctypes.data_as(dp),ctypes.byref(n),o.ctypes.data_as(dp),"
-            "z.ctypes.data_as(dp),ctypes.byref(n),t.ctypes.data_as(dp),ctypes.byref(n));print('survived')")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+            "z.ctypes.data_as(dp),ctypes.byref(n),t.ctypes.data_as(dp),ctypes.byref(n));print('survived', t[0])")
+    env = {k: v for k, v in os.environ.items() if k != "RTMI_ABORT_ON_ERROR"}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert p.returncode == 0 and "survived nan" in p.stdout
+    assert "librtmi: dff_ failed" in p.stderr
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env={**env, "RTMI_ABORT_ON_ERROR": "1"})
     assert p.returncode != 0 and "survived" not in p.stdout
     assert "librtmi: dff_ failed" in p.stderr
 

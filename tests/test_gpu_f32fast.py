@@ -124,3 +124,23 @@ def test_fast_path_preconditions_and_determinism():
     off2[5], dep2[9], off2[11] = np.nan, np.nan, np.inf
     t = run_fast(v, d, off2, dep2)
     assert t[5] == -999.0 and t[9] == -999.0 and t[11] == -999.0 and (t[np.r_[0:5, 12:256]] > 0).all()
+
+
+@pytest.mark.gpu
+def test_fast_path_negative_offsets_are_mirror_rays():
+    """costFunc is odd in p (subroutineR-quiet.f90:184-202): the reference, and the double-precision path, give a source at
+    offset -R the travel time of the source at R (and the ray parameter with the opposite sign).  The fast path's tolerances
+    are relative to the offset, so it solves for |R|: same times bit for bit, p negated, no extra sentinels."""
+    v, d = c5_model()
+    rng = np.random.default_rng(9)
+    n = 20_000
+    off, dep = rng.uniform(10, 8000, n), rng.uniform(50, d[-1] + 400, n)
+    tp, pp = run_fast(v, d, off, dep, want_p=True)
+    tm, pm = run_fast(v, d, -off, dep, want_p=True)
+    assert np.array_equal(tp, tm)
+    ray = ~np.isnan(pp)                                   # (top-layer sources carry no ray parameter)
+    assert np.array_equal(np.isnan(pp), np.isnan(pm)) and np.array_equal(pm[ray], -pp[ray])
+    assert (tm == -999.0).sum() == (tp == -999.0).sum() < 20
+    ref = O.oracle_dff(v, d, -off, dep)                   # the reference on the mirrored sources
+    ok = (ref != -999.0) & (tm != -999.0)
+    assert np.median(np.abs(tm[ok] - ref[ok])) < 1e-6 and np.quantile(np.abs(tm[ok] - ref[ok]), 0.999) < 1e-4

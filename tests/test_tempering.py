@@ -766,3 +766,38 @@ def test_speculative_step_is_exact(kat):
                     assert info["discarded"] > 0           # proposals behind an accepted one WERE evaluated and thrown away
         finally:
             rt.set_option("path", 0)
+
+
+@pytest.mark.gpu
+def test_device_sampler_keeps_a_sentinel_residual_finite(golden_batches):
+    """A source the reference gives up on (-999, subroutineR-quiet.f90:167-169) enters SUM(DresRT**2) as (t_obs + 999)^2 -- about
+    1e6 s^2 -- and the reference, the batch API and the host sampler all sum that as a finite number (loglhood.f90:165-199).  The
+    device sampler's exact accumulator must as well (its grid takes addends below 2^32 s^2; round 3's stopped at 2^20, i.e. at
+    observed times above 25 s, and reported +Inf): same SS as rtmi_loglhood_batch's plain double sum, to a relative 1e-13."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    g = golden_batches["c2_sentinels"]                                   # the twelve -999 sources of the C2 stream + neighbours
+    assert (g["timeP"] == -999.0).sum() == 12
+    rng = np.random.default_rng(5)
+    n = 4096                                                             # (enough sources for the fused kernel path)
+    off = np.concatenate([g["off"], rng.uniform(10, 8000, n - g["off"].size)])
+    dep = np.concatenate([g["dep"], rng.uniform(50, g["depths"][-1] + 500, n - g["dep"].size)])
+    rt.load_library(); rt.init(0)
+    obs = rng.uniform(26.0, 40.0, n)                                     # observed times above 25 s: (t_obs + 999)^2 > 2^20
+    rt.set_sources(off, dep, obs)
+    nl = g["depths"].size
+    V = np.zeros((1, 16)); D = np.zeros((1, 16)); V[0, :nl + 1] = g["vels"]; D[0, :nl] = g["depths"]
+    _, ss_batch = rt.loglhood_batch(V, D, np.array([nl], np.int32), np.array([0.05]), want_ss=True)
+    assert np.isfinite(ss_batch[0]) and ss_batch[0] > 12 * 1.0e6
+    pr = T.Prior(kmax=12)
+    h = raymod.NativeChains(4, 13, n, pr, seed=3)
+    nodes = np.column_stack([np.concatenate([[0.0], g["depths"]]), g["vels"]])
+    for i in range(4):
+        h.set_chain(i, nodes, 0.05, 1.0)
+    h.evaluate()
+    a = h.get_all()
+    assert np.all(np.isfinite(a["ss"])) and np.all(np.isfinite(a["logL"]))
+    assert np.all(np.abs(a["ss"] - ss_batch[0]) <= 1e-13 * ss_batch[0]), (a["ss"], ss_batch[0])
+    h.run(5, 0, None, 0)                                                  # and the chains can move: ratios are finite numbers
+    assert np.all(np.isfinite(h.get_all()["logL"]))
+    assert rt.load_library().rtmi_device_status() == 0
