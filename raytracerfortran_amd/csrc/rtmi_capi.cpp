@@ -303,6 +303,55 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
     return RTMI_OK;
 }
 
+int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains, int max_nlayers,
+                   const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus, const void *ptdev,
+                   size_t ptdev_bytes, const void *d_sweep_args, int nspec, unsigned int epoch, int parity, int nslots_k, hipStream_t stream,
+                   const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
+                   int part_stride, const rtmi::PtPend *d_pinfo)
+{
+    const Tuning tn = tuning_snapshot();
+    if (!batch_takes_fused(tn, nsrc) || !d_partial_x)
+        return -1;
+    int *d_status = nullptr;
+    int rc = status_word_for(stream, &d_status);
+    if (rc)
+        return rc;
+    rtmi::FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.d_vels = d_vels;
+    fa.d_depths = d_depths;
+    fa.d_nlayers = d_nlayers;
+    fa.ld_model = ld_model;
+    fa.refill_min = tn.refill_min;
+    fa.tail_group = tn.tail_group;
+    fa.retire_max = tn.retire_max;
+    fa.d_status = d_status;
+    fa.promote_age = tn.promote_age;
+    fa.allow_skip = 1;
+    fa.d_src_offset = d_src_offset;
+    fa.d_src_depth = d_src_depth;
+    fa.nsrc = nsrc;
+    fa.d_obs = d_obs;
+    fa.d_partial_x = d_partial_x;
+    fa.part_stride = part_stride;
+    fa.acc_atomic = 1;
+    fa.d_pinfo = d_pinfo;
+    if (d_inc && d_r2) {
+        fa.d_inc = d_inc;
+        fa.d_r2 = d_r2;
+        fa.d_inc_counts = d_inc_counts;
+    }
+    const hipError_t e = rtmi_launch_pt_prop(&fa, ptdev, ptdev_bytes, static_cast<const rtmi::PtSweepArgs *>(d_sweep_args), nspec, epoch,
+                                             parity, nslots_k, nchains, max_nlayers, cus, tn.solve_waves, stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the caller falls back
+        if (getenv("RTMI_PT_VERBOSE"))
+            fprintf(stderr, "rtmi: speculative sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
+        return -1;
+    }
+    return RTMI_OK;
+}
+
 int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,
                     const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus,
                     const void *ptdev, size_t ptdev_bytes, const void *d_queue_args, int nspec, unsigned int fin_target, int task_src,

@@ -250,7 +250,11 @@ __device__ __forceinline__ void stage_model(const LayerTable<T> &t, const T *__r
     }
     __syncthreads();
     if (t.HWR) {
-        const int n = t.row_len * t.row_len;
+        // one row per stack height a lane can have (r <= nlayers): with the constant row length of table form 1 that is
+        // (nlayers + 1) x 21 entries, not all 441 -- the sampler's k <= 10 models pay a quarter of the fill per staged model,
+        // and no entry of HW beyond the model's own is read
+        const int nrows = nlayers + 1 < t.row_len ? nlayers + 1 : t.row_len;
+        const int n = nrows * t.row_len;
         for (int e = threadIdx.x; e < n; e += blockDim.x) {
             const int r = e / t.row_len, i = e - r * t.row_len;
             LayerPair<T> v;

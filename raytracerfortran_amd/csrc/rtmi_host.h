@@ -93,6 +93,13 @@ int launch_pt_sweep(const double *d_vels, const double *d_depths, const int32_t 
                     const void *sweep_args, hipStream_t stream, const rtmi::PtInc *d_inc = nullptr, double *d_r2 = nullptr,
                     unsigned long long *d_inc_counts = nullptr, unsigned long long *d_partial_x = nullptr, int part_stride = 0);
 
+// The speculative sweep with the workgroups dealt to the chains in proportion to their slots (pt_sweep_prop_kernel): cooperative
+// launch; d_sweep_args = DEVICE copy of rtmi::PtSweepArgs (flag / count / abort_, walloc, nchains, nspec).
+int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int nchains, int max_nlayers,
+                   const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus, const void *ptdev,
+                   size_t ptdev_bytes, const void *d_sweep_args, int nspec, unsigned int epoch, int parity, int nslots_k, hipStream_t stream,
+                   const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
+                   int part_stride, const rtmi::PtPend *d_pinfo);
 // The speculative sweep over a task queue (rtmi_kernels.hip::pt_sweep_queue_kernel): an ordinary launch of one workgroup per
 // CU.  Non-zero = not available (the plain kernel path is selected): use the per-slot launches.
 int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,

@@ -131,6 +131,8 @@ struct PtSweepArgs {
     int nspec;             // > 0: the speculative step (rtmi_pt_dev.hpp::pt_step_spec) with this many model rows per chain; a
                            // chain runs passes until its sweep is complete (nslots_k only bounds them), `epoch` is a tag of
                            // the sweep (the passes of a sweep count from it, at most 4096)
+    int *walloc;           // speculative form: [2][nchains] weights (slots of the chain's sweep) by which the launch's workgroups
+    int parity;            // are dealt to the chains: read from walloc[parity], rewritten for the next sweep in walloc[1 - parity]
 };
 
 // Arguments of the tempering sampler's sweep as a persistent kernel over a TASK QUEUE (pt_sweep_queue_kernel): workgroups are
@@ -195,6 +197,12 @@ hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const void *ptdev, 
 hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtQueueArgs *d_q,
                                 int nspec, unsigned int fin_target, int max_nlayers, int num_cus, int waves_per_simd, int task_src,
                                 hipStream_t stream);
+// The speculative sweep with the launch's workgroups dealt to the chains in proportion to their slots (pt_sweep_prop_kernel):
+// cooperative launch of one workgroup per CU.  d_w: DEVICE copy of the constant words (flag, count, abort_, walloc, nchains,
+// nspec); epoch (tag of the sweep), parity (which half of walloc to read) and nslots_k (bound of the passes) per launch.
+hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtSweepArgs *d_w,
+                               int nspec, unsigned int epoch, int parity, int nslots_k, int nchains, int max_nlayers, int num_cus,
+                               int waves_per_simd, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check_f32(const float *d_w, const float *d_num, const float *d_den, int64_t n,
                                           unsigned long long *d_out, hipStream_t stream);
 hipError_t rtmi_launch_fastmath_check(const double *d_w, const double *d_num, const double *d_den, int64_t n,

@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void fused_kernel(FusedArgsT<
 // Memory: what one workgroup writes for another (model row, NL, partial sums) is written, fenced at device scope
 // (__threadfence) by its writers, and only then announced through an atomic; the reader takes the atomic with acquire
 // semantics at device scope and invalidates the scalar cache before it reads.
-__device__ __forceinline__ bool pt_wait_reached(volatile unsigned int *word, unsigned int target, volatile unsigned int *abort_word,
+__device__ __noinline__ bool pt_wait_reached(volatile unsigned int *word, unsigned int target, volatile unsigned int *abort_word,
                                                 int *d_status)
 {
     int polls = 0;
@@ -1352,16 +1352,178 @@ __device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chai
 
 __device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int chain, int begin, int wg_total)
 {
-    const rtmi_pt_dev::PtDev d = *dp;
-    if (d.K <= 16) {
-        if (threadIdx.x < 16)
+    const rtmi_pt_dev::PtDev d = *dp;  // (called by the 64 lanes of wave 0: the lane groups take the window's slots side by side)
+    if (threadIdx.x < 64) {
+        if (d.K <= 16)
             rtmi_pt_dev::pt_step_spec<16>(d, chain, begin, 0, wg_total);
-    } else if (d.K <= 32) {
-        if (threadIdx.x < 32)
+        else if (d.K <= 32)
             rtmi_pt_dev::pt_step_spec<32>(d, chain, begin, 0, wg_total);
-    } else if (threadIdx.x < 64) {
-        rtmi_pt_dev::pt_step_spec<64>(d, chain, begin, 0, wg_total);
+        else
+            rtmi_pt_dev::pt_step_spec<64>(d, chain, begin, 0, wg_total);
     }
+}
+
+// ---- the speculative sweep, workgroups dealt to the chains IN PROPORTION TO THEIR SLOTS ------------------------------------
+// With the speculative step (rtmi_pt_dev.hpp::pt_step_spec) a pass of a chain is up to nspec model rows side by side, and what
+// bounds a sweep is the chain with the most nodes: it has the most slots, hence the most passes, and with the same number of
+// workgroups for every chain (pt_sweep_kernel's layout) the others idle while it finishes.  Here the launch's workgroups (one
+// per CU) are dealt to the chains by weight = slots of the chain's sweep (2 k + 1, as the chain stood when its last sweep
+// ended): every chain at least one, the rest in proportion, so that passes x time-per-pass comes out about equal for all.
+// The weights are read from walloc[parity] -- written by the chains' leading workgroups at the end of the sweep before, into the
+// half nobody reads during that sweep -- so every workgroup of the launch computes the same layout.  Within a chain the
+// protocol is pt_sweep_kernel's: the leading workgroup takes the step and publishes it (flag), the chain's workgroups deal
+// themselves to the rows that go through the likelihood (workgroup w of gxc evaluates the a-th such row, a = w mod nact, as
+// share w / nact of ceil((gxc - a) / nact) -- or, with fewer workgroups than rows, every nact-th row on its own), add their
+// exact sums into the rows' accumulators and arrive (count).  A window of proposals that all lie below the deepest source needs
+// no pass at all: the leading workgroup takes the next step at once.
+// (The kernel around the likelihood body keeps next to nothing in registers: the body is at its register limit, and whatever
+// lives across it is paid for in spills inside its loops.  The layout, the handshakes and the steps are real calls; what a
+// workgroup has to remember between them -- its chain, its row, the pass -- sits in LDS.)
+enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_WORDS = 8 };
+
+__device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, volatile int *ctl)
+{
+    // first_c = c + floor(R P_c / W), R = nwg - nchains spare workgroups, P_c = weights before chain c; wave 0 calls
+    const int lane = threadIdx.x & 63, nwg = gridDim.x, nchains = wp->nchains;
+    const int *wts = wp->walloc + (size_t)parity * nchains;
+    long long W = 0;
+    for (int c0 = 0; c0 < nchains; c0 += 64) {
+        int wc = c0 + lane < nchains ? wts[c0 + lane] : 0;
+        wc = (c0 + lane < nchains && wc < 1) ? 1 : wc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            wc += __shfl_xor(wc, off, 64);
+        W += wc;
+    }
+    const long long R = nwg - nchains;
+    long long carry = 0;
+    for (int c0 = 0; c0 < nchains; c0 += 64) {
+        const int c = c0 + lane;
+        int wc = c < nchains ? wts[c] : 0;
+        wc = (c < nchains && wc < 1) ? 1 : wc;
+        int incl = wc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += o;
+        }
+        const long long P = carry + incl - wc;
+        const long long first = c + (R * P) / W;
+        const long long next = c + 1 < nchains ? (c + 1) + (R * (P + wc)) / W : nwg;
+        if (c < nchains && (long long)blockIdx.x >= first && (long long)blockIdx.x < next) {
+            ctl[PROP_CHAIN] = c;
+            ctl[PROP_ROW] = (int)((long long)blockIdx.x - first);
+            ctl[PROP_GX] = (int)(next - first);
+            ctl[PROP_BASE] = (int)__hip_atomic_load(wp->count + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+// The leading workgroup's part of a pass (wave 0 calls): the chain's step(s), the weight of the chain for the next sweep's
+// layout once its sweep is complete, the flag.  Leaves fin | nact in LDS.
+__device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, volatile int *ctl, int pass, unsigned int epoch,
+                                       int parity)
+{
+    const int chain = ctl[PROP_CHAIN], gx = ctl[PROP_GX];
+    int begin = pass == 0 ? 1 : 0, guard = 0, fin_ = 0, nact_ = 0;
+#pragma unroll 1
+    for (;;) {
+        pt_step_spec_call(dp, chain, begin, gx);
+        __threadfence();                  // the rows are out before the flag; and this workgroup (one L1) reads them afresh, too
+        __builtin_amdgcn_s_dcache_inv();  // ... and so does a step that follows at once (the chain's words are wave-uniform: scalar loads)
+        begin = 0;
+        fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin_ || nact_ > 0 || ++guard > 4 * RTMI_PT_MAX_K)
+            break;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (fin_)  // the weight of this chain in the NEXT sweep's layout
+            wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        __hip_atomic_store(wp->flag + chain, epoch + (unsigned int)pass + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// After the flag: what the chain does in this pass (thread 0 of every workgroup of the chain).  ctl[PROP_NACT] = rows to
+// evaluate, 0 = the chain's sweep is complete (or a guard ran out: flagged).
+__device__ __noinline__ void prop_read_pass(const rtmi_pt_dev::PtDev *dp, volatile int *ctl, int *d_status)
+{
+    const int chain = ctl[PROP_CHAIN];
+    const int fin = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nact = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!fin && nact <= 0 && d_status)
+        atomicOr(d_status, 16);  // never expected: the leading workgroup's guard ran out
+    ctl[PROP_NACT] = (fin || nact <= 0) ? 0 : nact;
+}
+
+// The end of a pass (thread 0): this workgroup's arrival; the leading workgroup waits for the chain's.
+__device__ __noinline__ void prop_arrive(const PtSweepArgs *wp, volatile int *ctl, int pass, int *d_status)
+{
+    const int chain = ctl[PROP_CHAIN];
+    __threadfence();
+    __hip_atomic_fetch_add(wp->count + chain, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (ctl[PROP_ROW] == 0)
+        ctl[PROP_GO] = pt_wait_reached(wp->count + chain, (unsigned int)ctl[PROP_BASE] + (unsigned int)(pass + 1) * (unsigned int)ctl[PROP_GX],
+                                       wp->abort_, d_status) ? 1 : 0;
+}
+
+template <int TF>
+__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp,
+                                                                             unsigned int epoch, int parity, int max_pass, int lds_ctl)
+{
+    using namespace rtmi_pt_dev;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    volatile int *ctl = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_raw) + lds_ctl);
+    if (threadIdx.x < 64)
+        prop_layout(wp, parity, ctl);
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass <= max_pass; ++pass) {
+        if (ctl[PROP_ROW] == 0) {
+            if (threadIdx.x < 64)
+                prop_lead(dp, wp, ctl, pass, epoch, parity);
+        } else if (threadIdx.x == 0) {
+            ctl[PROP_GO] = pt_wait_reached(wp->flag + ctl[PROP_CHAIN], epoch + (unsigned int)pass + 1u, wp->abort_, a.d_status) ? 1 : 0;
+        }
+        __syncthreads();
+        if (ctl[PROP_ROW] != 0 && !ctl[PROP_GO])
+            return;
+        if (threadIdx.x == 0)
+            prop_read_pass(dp, ctl, a.d_status);  // (written before the flag, read after it)
+        __builtin_amdgcn_s_dcache_inv();
+        __syncthreads();
+        const int nact = ctl[PROP_NACT];
+        if (nact <= 0)
+            return;  // the sweep of this chain is complete
+        {
+            // enough workgroups: this one is share row / nact of ceil((gx - a) / nact) of the a-th row, a = row mod nact;
+            // fewer workgroups than rows: it takes the rows row, row + gx, ... each on its own.  (One call site: the body is
+            // inlined, and a second copy of it doubles the kernel and its spills.)
+            const int row = ctl[PROP_ROW], gx = ctl[PROP_GX];
+            const bool many = nact <= gx;
+#pragma unroll 1
+            for (int ai = many ? row % nact : row; ai < nact; ai += many ? nact : gx) {
+                const int e = __builtin_amdgcn_readfirstlane(dp->alist[ctl[PROP_CHAIN] * wp->nspec + ai]);
+                fused_body<double, false, false, true, false, TF, true, true>(a, ctl[PROP_CHAIN] * wp->nspec + e, many ? ctl[PROP_ROW] / nact : 0,
+                                                                               many ? (ctl[PROP_GX] - ai + nact - 1) / nact : 1,
+                                                                               reinterpret_cast<double *>(lds_raw));
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0)
+            prop_arrive(wp, ctl, pass, a.d_status);
+        __syncthreads();
+        if (ctl[PROP_ROW] == 0) {
+            if (!ctl[PROP_GO])
+                return;
+            __builtin_amdgcn_s_dcache_inv();
+        }
+    }
+    // never expected: a chain that is not complete after 2 k + 2 passes
+    if (threadIdx.x == 0 && a.d_status)
+        atomicOr(a.d_status, 16);
 }
 
 // ---- the speculative sweep over a TASK QUEUE ------------------------------------------------------------------------
@@ -2146,6 +2308,45 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
                         "workgroups per CU %d\n", gx * nchains, threads, lds_bytes, hipGetErrorString(e), coop, per_cu);
     }
     return e;
+}
+
+extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtSweepArgs *d_w,
+                                          int nspec, unsigned int epoch, int parity, int nslots_k, int nchains, int max_nlayers,
+                                          int num_cus, int waves_per_simd, hipStream_t stream)
+{
+    using namespace rtmi;
+    using rtmi_pt_dev::PtDev;
+    if (!args || !ptdev || !d_w || ptdev_bytes != sizeof(PtDev) || !args->d_obs || !args->d_nlayers || args->d_timeP || !args->d_partial_x ||
+        nspec < 1 || nspec > PT_SPEC_MAX || nchains < 1 || nchains > num_cus)
+        return hipErrorInvalidValue;
+    {
+        const hipError_t e = prepare_fused_t<double>();
+        if (e != hipSuccess)
+            return e;
+    }
+    FusedArgs a = *args;
+    const PtDev *dp = static_cast<const PtDev *>(ptdev);  // a DEVICE copy of the handle's view
+    a.max_nlayers = max_nlayers;
+    a.rows = RTMI_TABLE_FORM(max_nlayers);
+    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
+    a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
+    // one workgroup per CU with as large a record area as a CU holds: a chain with few workgroups takes a row in several rounds
+    size_t lds_bytes = 0;
+    int threads = 0;
+    (void)rtmi_fused_geometry(a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads, &a.slots, &lds_bytes);
+    int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
+    lds_bytes = (size_t)lds_ctl + 4 * PROP_WORDS;
+    if (lds_bytes > 160 * 1024 || threads < 64)
+        return hipErrorInvalidValue;
+    if (a.rows == 2)
+        a.rows = 0;  // (as in rtmi_launch_pt_sweep: form 0 with the body inlined into a loop)
+    const void *fn = a.rows == 1 ? reinterpret_cast<const void *>(&pt_sweep_prop_kernel<1>) : reinterpret_cast<const void *>(&pt_sweep_prop_kernel<0>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)
+        return e;
+    int max_pass = 2 * nslots_k + 2;  // a pass retires at least one slot of the chain
+    void *kargs[7] = {&a, &dp, &d_w, &epoch, &parity, &max_pass, &lds_ctl};
+    return hipLaunchCooperativeKernel(fn, dim3((unsigned)num_cus), dim3((unsigned)threads), kargs, lds_bytes, stream);
 }
 
 extern "C" hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,

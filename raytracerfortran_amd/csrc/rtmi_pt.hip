@@ -73,8 +73,7 @@ __global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_kernel(PtDev d, int d
 template <int G>
 __global__ __launch_bounds__(PT_STEP_THREADS) void pt_step_spec_kernel(PtDev d, int begin, int eval)
 {
-    constexpr int CPB = PT_STEP_THREADS / G;  // chains per block
-    const int c = blockIdx.x * CPB + threadIdx.x / G;
+    const int c = blockIdx.x * (PT_STEP_THREADS / 64) + threadIdx.x / 64;  // one WAVE per chain: its lane groups take the window's slots side by side
     if (c >= d.nchains)
         return;
     pt_step_spec<G>(d, c, begin, eval, 0);
@@ -107,6 +106,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
             d.NL[m + e] = 0;
         d.nwin[c] = 1;
         d.nact[c] = 1;
+        d.wend[c] = 0;
+        d.winv[c] = 0;
         d.alist[m] = 0;
         d.rowwg[m] = d.gx_launch;
         o->pending = d.pend_i[4 * c + 0];
@@ -259,6 +260,10 @@ struct rtmi_pt {
     unsigned long long *d_qstats = nullptr;  // RTMI_PT_QSTATS: where the workgroups' time went (printed by rtmi_pt_run)
     unsigned int q_fin_target = 0;   // chains completed over all queue launches so far
     int task_src = 0, task_fine = 0;
+    bool use_queue = false;          // RTMI_PT_QUEUE=1: the task-queue engine instead of the proportional layout (A/B)
+    int *d_walloc = nullptr;         // [2][nchains] (rtmi_pt_dev.hpp::PtDev::walloc)
+    int sweep_parity = 0;
+    rtmi::PtSweepArgs *d_wprop = nullptr;  // device copy of the proportional engine's constant words
     std::vector<rtmi::PtInc> inc0;   // (one-at-a-time step) the rows of the residual slab never change: a chain's record as reset by rtmi_pt_set_chain
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -290,7 +295,7 @@ void launch_step(rtmi_pt *h, int decide, int sigma, int propose, int ivo, int ip
 void launch_step_spec(rtmi_pt *h, int begin, int eval)
 {
     const int G = h->K <= 16 ? 16 : (h->K <= 32 ? 32 : 64);
-    const int cpb = PT_STEP_THREADS / G;
+    const int cpb = PT_STEP_THREADS / 64;
     const dim3 g((h->nchains + cpb - 1) / cpb), b(PT_STEP_THREADS);
     if (G == 16)
         hipLaunchKernelGGL(pt_step_spec_kernel<16>, g, b, 0, h->stream, h->d, begin, eval);
@@ -384,7 +389,25 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
                 (void)hipEventRecord(e, s);
         }
     };
-    if (engine == 1 && h->use_persistent && h->spec && h->d_qslots && h->d_ptdev && h->d_partial_x) {
+    if (engine == 1 && h->use_persistent && h->spec && !h->use_queue && h->nchains <= h->cus && h->d_ptdev && h->d_partial_x) {
+        // the speculative sweep, workgroups dealt to the chains in proportion to their slots: one cooperative launch
+        if (ev0)
+            HIP_TRY(hipEventRecord(ev0, h->stream));
+        Closer closer{ev1, h->stream};
+        const size_t n = (size_t)h->nsrc;
+        if (launch_pt_prop(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc, h->d_set + 2 * n,
+                           h->cus, h->d_ptdev, sizeof h->d, h->d_wprop, h->nspec, h->epoch, h->sweep_parity, ks, h->stream,
+                           h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride,
+                           h->d_pinfo) == RTMI_OK) {
+            h->epoch += 4096u;  // (the passes of a sweep count from a tag of its own)
+            h->sweep_parity ^= 1;
+            h->launches += 1;
+            return RTMI_OK;
+        }
+        h->use_persistent = false;
+        h->engine = 0;
+        closer.e = nullptr;
+    } else if (engine == 1 && h->use_persistent && h->spec && h->use_queue && h->d_qslots && h->d_ptdev && h->d_partial_x) {
         // the speculative sweep over the task queue: one ordinary launch of a workgroup per CU
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
@@ -592,6 +615,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_pend_z, 3 * nc * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&h->d_pinfo, 2 * nr * sizeof(rtmi::PtPend)) == hipSuccess &&
               hipMalloc((void **)&h->d_cdf, (size_t)ncdf * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&h->d_walloc, 2 * nc * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_qctl, (32 * RTMI_PTQ_RINGS + 32 + 2 * nc) * sizeof(unsigned int)) == hipSuccess &&
               (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nr * (size_t)pstride * sizeof(unsigned long long)) == hipSuccess);
     // The residual cache of the incremental likelihood (the chains' current residuals + one row per model row, twice with the
@@ -623,6 +647,23 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         h->qmask = (unsigned int)(cap - 1);
         ok = hipMalloc((void **)&h->d_qslots, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long)) == hipSuccess &&
              hipMemsetAsync(h->d_qslots, 0, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long), h->stream) == hipSuccess;
+    }
+    if (ok) {
+        std::vector<int> w0(2 * nc, 3);  // (k = 1)
+        ok = hipMemcpy(h->d_walloc, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (const char *e = getenv("RTMI_PT_QUEUE"))
+        h->use_queue = strcmp(e, "0") != 0;
+    if (ok) {
+        rtmi::PtSweepArgs w;
+        memset(&w, 0, sizeof w);
+        w.nchains = h->nchains;
+        w.flag = h->d_sync;
+        w.count = h->d_sync + h->nchains;
+        w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
+        w.nspec = h->nspec;
+        w.walloc = h->d_walloc;
+        ok = hipMalloc((void **)&h->d_wprop, sizeof w) == hipSuccess && hipMemcpy(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice) == hipSuccess;
     }
     const size_t nqctl = 32 * RTMI_PTQ_RINGS + 32 + 2 * nc;
     if (ok)
@@ -789,6 +830,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.pctr = h->d_spec_u64 + nc;
         d.pend_z = h->d_pend_z;
         d.pinfo = h->d_pinfo;
+        d.walloc = h->d_walloc;
         d.acc = h->d_partial_x;
         // one-at-a-time step: a chain's rows of the residual slab never change (current residuals: row c; its proposal's: row
         // nchains + c); the speculative step writes them with every proposal
@@ -834,7 +876,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
                     h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x,
-                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qslots, h->d_qctl, h->d_qargs, h->d_qstats};
+                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qslots, h->d_qctl, h->d_qargs, h->d_qstats, h->d_walloc, h->d_wprop};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -865,6 +907,9 @@ int rtmi_pt_set_chain(rtmi_pt *h, int chain, int k, const double *depths, const 
         HIP_TRY(hipMemsetAsync(h->d.cur + c, 0, sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(h->d.fin + c, 0, sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(h->d.pend_i + 4 * c, 0, 4 * sizeof(int), h->stream));
+        const int wk = 2 * k + 1;
+        HIP_TRY(hipMemcpyAsync(h->d_walloc + c, &wk, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_walloc + h->nchains + c, &wk, sizeof(int), hipMemcpyHostToDevice, h->stream));
     } else {
         HIP_TRY(hipMemcpyAsync(h->d_inc + c, &h->inc0[c], sizeof(rtmi::PtInc), hipMemcpyHostToDevice, h->stream));
     }

@@ -75,6 +75,8 @@ struct PtDev {
     unsigned long long *acc;  // [rows][part_stride][4] = partial_x, writable: the step zeroes the accumulator of every row it proposes
     int gx_launch;        // per-slot engine: workgroups per row of the batched launch (rowwg of every evaluated row)
     int task_src;         // queue engine: sources per task -- a row is evaluated as ceil(loaded sources / task_src) tasks
+    int *walloc;          // [2][nchains] weights (slots of the chain's sweep, 2 k + 1) by which pt_sweep_prop_kernel deals its
+                          // workgroups to the chains; an evaluation (rtmi_pt_evaluate) refreshes both halves
 };
 
 // Sources [0, prefix_above(d, z)) of the handle's depth-sorted set have depths < z: one load from the depth histogram (a
@@ -121,7 +123,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     int k = d.k[c];
     const int act = d.pactive[c];
     const int pk = d.pk[c];
-    const unsigned long long ctr0 = d.ctr[c];
+    const unsigned long long nsw = d.ctr[c];  // sweeps this chain has completed: the random draws are indexed by (sweep, slot, purpose)
+    const int pslot = d.pslot[c];             // the slot whose proposal awaits its decision
     double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
     const double beta = d.beta[c], plp = d.plp[c];
     const rtmi::PtInc ic = d.inc[c];  // of the proposal that has just been evaluated (if any)
@@ -146,7 +149,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
         }
     }
     long long *st = d.stats + (size_t)c * 8;
-    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr0);
+    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, 0);
 
     // ---- decision of the slot whose likelihood has just been evaluated (prjmh_temper_rf.f90:697-706, :742-751) ----
     if (decide != PT_NONE && act != 0) {
@@ -164,7 +167,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 lr = 50.0;
             if (lead)
                 st[2 * decide + 1] += 1;
-            const double u_acc = R::philox_uniform(rng);
+            const double u_acc = R::draw_uniform(rng, nsw, pslot, R::DRAW_ACCEPT);
             // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects
             if (lr == lr && !(u_acc >= exp(lr))) {
                 k = pk;
@@ -206,9 +209,9 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630); same rays, so the residual sum is reused ----------
     if (sigma) {
-        if (R::philox_uniform(rng) >= 0.10) {
+        if (R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_MOVE) >= 0.10) {
             const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
-            const double sd_new = sd + step * R::philox_normal(rng);
+            const double sd_new = sd + step * R::draw_normal(rng, nsw, R::SLOT_SIGMA);
             if (lead)
                 st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
@@ -218,7 +221,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 double lr = (logl_new - logL) * beta;
                 if (lr > 50.0)
                     lr = 50.0;
-                const double u_acc = R::philox_uniform(rng);
+                const double u_acc = R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_ACCEPT);
                 if (lr == lr && !(u_acc >= exp(lr))) {
                     sd = sd_new;
                     logL = logl_new;
@@ -234,10 +237,11 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
         d.ss[c] = ss;
     }
     if (propose == PT_NONE) {
-        if (lead)
-            d.ctr[c] = rng.index;
+        if (lead && sigma)
+            d.ctr[c] = nsw + 1ull;  // (the step with the sigma move ends the chain's sweep)
         return;  // launch-uniform
     }
+    const int slot = propose == PT_BD ? 0 : 2 * ivo + ipar;
 
     // ---- proposal of the next slot --------------------------------------------------------------------------------
     // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the chain-dependent branches.
@@ -269,7 +273,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     if (propose == PT_BD) {
         // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
         if (p.kmin != p.kmax) {
-            const double u = R::philox_uniform(rng);
+            const double u = R::draw_uniform(rng, nsw, 0, R::DRAW_MOVE);
             int move;
             if (k == p.kmax)
                 move = (u <= 0.3333) ? 2 : 0;
@@ -278,8 +282,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
             else
                 move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
             if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
-                const double zn = (p.hmx - p.hmin) * R::philox_uniform(rng);
-                const double vn = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
+                const double zn = (p.hmx - p.hmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_A);
+                const double vn = p.vmin + (p.vmax - p.vmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_B);
                 if (i == k) {
                     zi = zn;
                     vi = vn;
@@ -290,7 +294,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
                 moved_node = k;
                 zthr = zn;
             } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
-                int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
+                int idel = 1 + (int)(R::draw_uniform(rng, nsw, 0, R::DRAW_A) * (k - 1));
                 if (idel > k - 1)
                     idel = k - 1;
                 if (i >= idel && i + 1 < k) {
@@ -307,7 +311,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     } else if (ivo < k) {
         // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
         const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
-        const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
+        const double step = scale * tan(3.141592653589793 * (R::draw_uniform(rng, nsw, slot, R::DRAW_MOVE) - 0.5));
         if (i == ivo) {
             if (ipar == 0)
                 zi += step;
@@ -404,7 +408,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
     }
     if (lead) {
         d.NL[c] = nl;
-        d.ctr[c] = rng.index;
+        d.pslot[c] = slot;
     }
 }
 
@@ -413,20 +417,28 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // The SPECULATIVE step (exact: chains advance bit for bit as with pt_step_group).
 //
 // A perturbation is accepted about one time in five, so four times in five the state after a proposal slot is the state
-// before it; and the chain's random stream is counter-based, so the proposals of the slots s, s + 1, ... ASSUMING EVERY ONE
-// OF THEM IS REJECTED are all known at once -- each is drawn from the same model, at a stream position that is fixed by the
-// draws of the ones before it.  One step therefore proposes a WINDOW of up to `nspec` models (one model row each,
-// m = chain * nspec + e), one likelihood pass evaluates them side by side, and the next step walks their decisions IN ORDER
-// with the very acceptance draws the one-at-a-time sampler would take: the first accepted entry becomes the state, the
-// entries behind it are discarded (they were drawn from a state that no longer is the chain's) and the chain goes on from
-// the slot after it; if none is accepted the whole window is retired.  Same draws, same sums (they are exact integers), same
-// decisions: prjmh_temper_rf.f90:721-759 (sequential perturbations), :669-713 (birth / death), :561-569 (sigma) are run
-// as written, only the likelihoods are evaluated ahead of time.
+// before it; and the chain's draws are indexed by (sweep, slot, purpose) (rtmi_pt_rules.h), so the proposals of the slots
+// s, s + 1, ... ASSUMING EVERY ONE OF THEM IS REJECTED are all known at once -- each is drawn from the same model with draws
+// that depend on nothing but its slot.  One step therefore proposes a WINDOW of up to `nspec` slots (one model row for
+// each proposal that falls inside the prior, m = chain * nspec + e), one likelihood pass evaluates the rows side by side,
+// and the next step takes their decisions with the very acceptance draws the one-at-a-time sampler would take: the first
+// accepted entry (in slot order) becomes the state, the entries behind it are discarded (they were drawn from a state that
+// no longer is the chain's) and the chain goes on from the slot after it; if none is accepted the whole window is retired.
+// Same draws, same sums (they are exact integers), same decisions: prjmh_temper_rf.f90:721-759 (sequential perturbations),
+// :669-713 (birth / death), :561-569 (sigma) are run as written, only the likelihoods are evaluated ahead of time.
+//
+// ONE WAVE PER CHAIN, THE WINDOW'S SLOTS SIDE BY SIDE: the wave's 64 lanes are 64 / G groups of G lanes (G = 16, 32, 64 >= K);
+// every group holds the chain's nodes (lane i of a group = node i) and works on a slot of its own -- group g of round r takes
+// the window's slot r (64 / G) + g: the proposal (draws, bounds, depth order, model row, what the likelihood needs to know)
+// when the window is made, the decision (likelihood, acceptance draw, ratio) when it comes back.  A proposal costs a lone
+// wave about 6 us of dependent instructions; four of them one after the other were more than the likelihood pass they
+// prepare (round 4, profiles/r04a/queue_v3_timings.txt: 77 us per step at four rows).  With K <= 16 a window of four is one
+// round; K <= 32 takes two, K <= 64 four.
 //
 // Per chain: `cur` = its next undecided slot (0 = birth/death, s = (node s >> 1, parameter s & 1); a chain with k nodes has
 // the slots 0 .. 2k - 1, then the sigma move; slots of nodes it does not have do not exist for it), `fin` = the sweep is
-// complete.  Proposals outside the prior cost no model row and no acceptance draw; they are counted when the entries around
-// them are decided (pinv / winv), so that the statistics are those of the one-at-a-time sampler as well.
+// complete.  Proposals outside the prior cost no model row; they are counted when the window is decided (winv), so that
+// the statistics are those of the one-at-a-time sampler as well.
 // Incremental likelihood: the rows of a window all read the chain's current residuals (r2cur, or the pending accepted
 // proposal's row) and write rows of their own; the two sets of proposal rows alternate whenever a proposal is accepted, so no
 // row is read and written in the same pass, and exactly one row of a pass (the first that is evaluated) moves the pending
@@ -435,15 +447,24 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // wg_total: > 0 workgroups the chain's rows share in the next pass (they are dealt to the evaluated rows round-robin),
 // 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows), < 0 = queue engine: a row is
 // cut into tasks of about -wg_total loaded sources.
-#define PT_SPEC_MAX 4  // (the window's records are held in registers; the step shares the sweep kernel's 128)
+// Called by ALL 64 lanes of a wave for one chain.
+#define PT_SPEC_MAX 4
 
 template <int G>
 __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const int begin, const int eval, const int wg_total)
 {
     namespace R = rtmi_pt_rules;
+    constexpr int NG = 64 / G;                              // slots worked on side by side
+    constexpr int NR = (PT_SPEC_MAX + NG - 1) / NG;         // rounds a window can take
     const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
     const int i = lane - gbase;               // the node this lane holds
+    const int g = lane / G;                   // this lane's group
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gbase;
+    // one bit per group: its leading lane
+    unsigned long long leads = 0ull;
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        leads |= 1ull << (q * G);
     const int K = d.K, D = d.nspec;
     const rtmi_pt_prior &p = d.pr;
     const bool lead = i == 0;
@@ -454,152 +475,147 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     double zi = d.z[row], vi = d.v[row];
     const double lpk_lo = d.logpk[i < K + 2 ? i : K + 1], lpk_hi = d.logpk[i + G < K + 2 ? i + G : K + 1];
     int k = d.k[c];
-    unsigned long long ctr = d.ctr[c];
+    unsigned long long nsw = d.ctr[c];        // sweeps completed: the draws are indexed by (sweep, slot, purpose)
     double sd = d.sd[c], logL = d.logL[c], ss = d.ss[c];
     const double beta = d.beta[c];
     int cache_ok = d.cache_valid[c];
     int cur = begin ? 0 : d.cur[c];
     int fin = begin ? 0 : d.fin[c];
-    const int nwin = begin ? -1 : d.nwin[c];  // -1: no window awaits its decisions; 0: one without entries (its draws and its proposals outside the prior still count)
+    const int nwin = begin ? -1 : d.nwin[c];  // -1: no window awaits its decisions; 0: one without entries (its proposals outside the prior still count)
     const int wend = d.wend[c], winv = d.winv[c];
-    const unsigned long long wctr = d.wctr[c];
+    const int nact_prev = d.nact[c];
     int wbuf = d.wbuf[c];
     int pending = d.pend_i[4 * c + 0], pend_idx = d.pend_i[4 * c + 1];
-    // everything the decisions need, in ONE round trip: the entries' records, their exact sums (the row's accumulator:
-    // three limbs + flags, added up by the row's workgroups with 64-bit atomics) and this lane's node of every entry
-    int e_act[PT_SPEC_MAX], e_pk[PT_SPEC_MAX], e_slot[PT_SPEC_MAX], e_inv[PT_SPEC_MAX];
-    unsigned long long e_ctr[PT_SPEC_MAX], e_a0[PT_SPEC_MAX], e_a1[PT_SPEC_MAX], e_a2[PT_SPEC_MAX], e_a3[PT_SPEC_MAX];
-    double e_lp[PT_SPEC_MAX], e_pz[PT_SPEC_MAX], e_pv[PT_SPEC_MAX];
+    // this group's entries of the window (one per round): everything the decision needs
+    int e_act[NR], e_pk[NR], e_slot[NR];
+    double e_lp[NR], e_pz[NR], e_pv[NR], e_part[NR];
 #pragma unroll
-    for (int e = 0; e < PT_SPEC_MAX; ++e) {
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * NG + g;
         const bool on = e < D && e < nwin;
         const int m = m0 + (on ? e : 0);
-        e_act[e] = on ? d.pactive[m] : 0;
-        e_pk[e] = on ? d.pk[m] : 0;
-        e_slot[e] = on ? d.pslot[m] : 0;
-        e_inv[e] = on ? d.pinv[m] : 0;
-        e_ctr[e] = on ? d.pctr[m] : 0ull;
-        e_lp[e] = on ? d.plp[m] : 0.0;
-        e_pz[e] = on ? d.pz[(size_t)m * K + ic_] : 0.0;
-        e_pv[e] = on ? d.pv[(size_t)m * K + ic_] : 0.0;
+        e_act[r] = on ? d.pactive[m] : 0;
+        e_pk[r] = on ? d.pk[m] : 0;
+        e_slot[r] = on ? d.pslot[m] : 0;
+        e_lp[r] = on ? d.plp[m] : 0.0;
+        e_pz[r] = on ? d.pz[(size_t)m * K + ic_] : 0.0;
+        e_pv[r] = on ? d.pv[(size_t)m * K + ic_] : 0.0;
+        // the row's exact sum: three limbs + flags, added up by the row's workgroups with 64-bit atomics
         const unsigned long long *w = d.partial_x + 4 * (size_t)m * d.part_stride;
-        e_a0[e] = on ? w[0] : 0ull;
-        e_a1[e] = on ? w[1] : 0ull;
-        e_a2[e] = on ? w[2] : 0ull;
-        e_a3[e] = on ? w[3] : 0ull;
-    }
-    // SUM(DresRT**2) of every evaluated entry
-    double e_part[PT_SPEC_MAX];
-#pragma unroll
-    for (int e = 0; e < PT_SPEC_MAX; ++e) {
+        const unsigned long long a0 = on ? w[0] : 0ull, a1 = on ? w[1] : 0ull, a2 = on ? w[2] : 0ull, a3 = on ? w[3] : 0ull;
         rtmi::Acc192 tot;
-        tot.w0 = e_a0[e] + (e_a1[e] << 48);
-        tot.w1 = ((e_a1[e] >> 16) + (e_a2[e] << 32) + (tot.w0 < e_a0[e] ? 1ull : 0ull)) | (e_a3[e] & RTMI_ACC_FLAGS);
-        e_part[e] = rtmi::acc_to_double(tot);
+        tot.w0 = a0 + (a1 << 48);
+        tot.w1 = ((a1 >> 16) + (a2 << 32) + (tot.w0 < a0 ? 1ull : 0ull)) | (a3 & RTMI_ACC_FLAGS);
+        e_part[r] = rtmi::acc_to_double(tot);
     }
     long long *st = d.stats + (size_t)c * 8;
-    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, ctr);
+    R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, 0);
 
-    // ---- decisions of the window, in order (prjmh_temper_rf.f90:697-706, :742-751) -------------------------------------
-    bool taken = false, had_eval = false;
-    int e_acc = -1, n_after = 0;
+    // ---- decisions of the window (prjmh_temper_rf.f90:697-706, :742-751): every group its entry, then the first in order ---
+    bool taken = false;
+    int acc_slot = 1 << 30;   // slot of the accepted entry (the window's proposals outside the prior count up to it)
+    int n_eval_upto = 0;      // evaluated entries up to and including the accepted one
     long long d_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < PT_SPEC_MAX; ++e) {
-        if (e < D && e < nwin) {
-            const int act = e_act[e];
-            had_eval = had_eval || act == 1 || act == 2;
-            if (taken) {
-                n_after += act == 1 ? 1 : 0;  // evaluated for nothing: drawn from a state that is not the chain's any more
-            } else {
-                d_st[1] += e_inv[e] & 0xFF;   // proposed, rejected outside the prior (:707-711)
-                d_st[3] += e_inv[e] >> 8;
-                const double part = act == 3 ? ss : e_part[e];  // (3: no source is affected -- the sum IS the current one)
-                // a NaN likelihood (NaN data, an unusable model row) is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
-                double logl_new = R::gaussian_loglike(part, d.ndata, sd);
-                if (logl_new != logl_new)
-                    logl_new = -1.7976931348623157e308;
-                if (act == 2) {
-                    ss = part;
-                    logL = logl_new;
-                    taken = true;
-                    e_acc = e;
-                } else {
-                    const int kind = e_slot[e] == 0 ? (int)PT_BD : (int)PT_MH;
-                    double lr = e_lp[e] + (logl_new - logL) * beta;
-                    if (lr > 50.0)
-                        lr = 50.0;
-                    d_st[2 * kind + 1] += 1;
-                    d_st[6] += 1;  // a model that went through the likelihood and was decided
-                    rng.index = e_ctr[e];
-                    const double u_acc = R::philox_uniform(rng);
-                    ctr = rng.index;
-                    cur = e_slot[e] + 1;
-                    // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects
-                    if (lr == lr && !(u_acc >= exp(lr))) {
-                        k = e_pk[e];
-                        ss = part;
-                        logL = logl_new;
-                        d_st[2 * kind] += 1;
-                        taken = true;
-                        e_acc = e;
-                    }
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * NG + g;
+        const bool mine = !taken && e < D && e < nwin;      // (group-uniform)
+        const int act = e_act[r];
+        const double part = act == 3 ? ss : e_part[r];      // (3: no source is affected -- the sum IS the current one)
+        // a NaN likelihood (NaN data, an unusable model row) is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
+        double logl_new = R::gaussian_loglike(part, d.ndata, sd);
+        if (logl_new != logl_new)
+            logl_new = -1.7976931348623157e308;
+        double lr = e_lp[r] + (logl_new - logL) * beta;
+        if (lr > 50.0)
+            lr = 50.0;
+        const double u_acc = R::draw_uniform(rng, nsw, e_slot[r], R::DRAW_ACCEPT);
+        // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects; an evaluation
+        // of the current state (2) is always "taken"
+        const bool acc = mine && (act == 2 || (lr == lr && !(u_acc >= exp(lr))));
+        const unsigned long long macc = __ballot(acc) & leads, mmine = __ballot(mine) & leads;
+        const int gfirst = macc ? (__ffsll((long long)macc) - 1) / G : NG;   // the first group (= entry, = slot) that accepts
+        // entries decided in this round: the groups up to the accepting one
+        const bool decided = mine && g <= gfirst;
+        const unsigned long long mdec = __ballot(decided && act != 2) & leads;
+        const unsigned long long mdec_bd = __ballot(decided && act != 2 && e_slot[r] == 0) & leads;
+        const unsigned long long mdec_ev = __ballot(decided && (act == 1 || act == 2)) & leads;
+        d_st[1] += __popcll(mdec_bd);
+        d_st[3] += __popcll(mdec) - __popcll(mdec_bd);
+        d_st[6] += __popcll(mdec);   // models that went through the likelihood and were decided
+        n_eval_upto += __popcll(mdec_ev);
+        (void)mmine;
+        if (macc) {
+            // the accepting group's entry becomes the state: its scalars and this lane's node from the lane that holds it
+            const int src = gfirst * G;
+            const int a_act = __shfl(act, src, 64), a_pk = __shfl(e_pk[r], src, 64), a_slot = __shfl(e_slot[r], src, 64);
+            const double a_part = __shfl(part, src, 64), a_logl = __shfl(logl_new, src, 64);
+            const double a_pz = __shfl(e_pz[r], src + i, 64), a_pv = __shfl(e_pv[r], src + i, 64);
+            ss = a_part;
+            logL = a_logl;
+            taken = true;
+            if (a_act != 2) {
+                k = a_pk;
+                acc_slot = a_slot;
+                cur = a_slot + 1;
+                d_st[a_slot == 0 ? 0 : 2] += 1;
+                if (i < k) {  // the proposal becomes the state
+                    zi = a_pz;
+                    vi = a_pv;
                 }
+            }
+            if (a_act != 3) {
+                // ITS residuals (in its row, for the sources it affected) are the pending ones now, and the chain's next
+                // rows write the other set; a model evaluated in full makes the cache valid
+                pending = 2;  // (set below, after the pass that evaluated this window is accounted for)
+                pend_idx = (wbuf * d.nchains + c) * D + (r * NG + gfirst) + 1;  // its record was written when it was proposed
             }
         }
     }
     if (nwin >= 0) {
-        if (!taken) {  // the whole window is retired
-            cur = wend;
-            ctr = wctr;
-            d_st[1] += winv & 0xFF;
-            d_st[3] += winv >> 8;
-        }
-        d_st[7] += n_after;
-        // The pass that evaluated this window has moved the residuals of an earlier accepted proposal to r2cur (its mover
-        // row).  If an evaluated entry is taken, ITS residuals (in its row, for the sources it affected) are the pending ones
-        // now, and the chain's next rows write the other set; a model evaluated in full makes the cache valid.
-        if (had_eval)
-            pending = 0;
-        if (taken) {
-            int a_act = 0;
-            double a_pz = 0.0, a_pv = 0.0;
+        if (!taken)
+            cur = wend;  // the whole window is retired
+        // the window's proposals outside the prior (:707-711), up to the accepted slot: bit j of winv = slot wbase + j
+        {
+            const int wbase = wend - (winv >> 8);  // (winv: invalid-slot bits | slots covered << 8)
+            int nbd = 0, nmh = 0;
 #pragma unroll
-            for (int e = 0; e < PT_SPEC_MAX; ++e)
-                if (e == e_acc) {
-                    a_act = e_act[e];
-                    a_pz = e_pz[e];
-                    a_pv = e_pv[e];
+            for (int j = 0; j < PT_SPEC_MAX; ++j)
+                if (((winv >> j) & 1) && wbase + j < acc_slot) {
+                    nbd += wbase + j == 0 ? 1 : 0;
+                    nmh += wbase + j == 0 ? 0 : 1;
                 }
-            if (a_act != 2) {  // the proposal becomes the state
-                if (i < k) {
-                    zi = a_pz;
-                    vi = a_pv;
-                    d.z[row] = zi;
-                    d.v[row] = vi;
-                }
-                if (lead)
-                    d.k[c] = k;
+            d_st[1] += nbd;
+            d_st[3] += nmh;
+        }
+        d_st[7] += nact_prev - n_eval_upto > 0 && taken ? nact_prev - n_eval_upto : 0;  // evaluated for nothing
+        // The pass that evaluated this window has moved the residuals of an earlier accepted proposal to r2cur (its mover row)
+        if (nact_prev > 0 && pending == 1)
+            pending = 0;
+        if (pending == 2) {
+            pending = 1;
+            wbuf ^= 1;
+            if (!cache_ok) {  // (without a valid cache every proposal is evaluated in full: this one was)
+                cache_ok = 1;
+                if (lane == 0)
+                    d.cache_valid[c] = 1;
             }
-            if (a_act != 3) {
-                pending = 1;
-                pend_idx = (wbuf * d.nchains + c) * D + e_acc + 1;  // its record was written when it was proposed
-                wbuf ^= 1;
-                if (!cache_ok) {  // (without a valid cache every proposal is evaluated in full: this one was)
-                    cache_ok = 1;
-                    if (lead)
-                        d.cache_valid[c] = 1;
-                }
+        }
+        if (taken && g == 0) {
+            if (lead)
+                d.k[c] = k;
+            if (i < k && i < K) {
+                d.z[row] = zi;
+                d.v[row] = vi;
             }
         }
     }
 
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630) once every slot of the sweep is decided ------------------
     if (!eval && !fin && cur >= 2 * k) {
-        rng.index = ctr;
-        if (R::philox_uniform(rng) >= 0.10) {
+        if (R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_MOVE) >= 0.10) {
             const double step = (p.sdmax - p.sdmin) / p.pertsdsdsc;
-            const double sd_new = sd + step * R::philox_normal(rng);
+            const double sd_new = sd + step * R::draw_normal(rng, nsw, R::SLOT_SIGMA);
             d_st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
                 double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
@@ -608,7 +624,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 double lr = (logl_new - logL) * beta;
                 if (lr > 50.0)
                     lr = 50.0;
-                const double u_acc = R::philox_uniform(rng);
+                const double u_acc = R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_ACCEPT);
                 if (lr == lr && !(u_acc >= exp(lr))) {
                     sd = sd_new;
                     logL = logl_new;
@@ -616,14 +632,14 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 }
             }
         }
-        ctr = rng.index;
+        nsw += 1ull;  // the chain's sweep is complete
         fin = 1;
     }
-    if (lead) {
+    if (lane == 0) {
         d.sd[c] = sd;
         d.logL[c] = logL;
         d.ss[c] = ss;
-        d.ctr[c] = ctr;
+        d.ctr[c] = nsw;
         d.cur[c] = cur;
         d.fin[c] = fin;
         d.wbuf[c] = wbuf;
@@ -635,8 +651,8 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 st[j] += d_st[j];
     }
 
-    // ---- the next window: proposals of the slots cur, cur + 1, ... all drawn from the chain's state ----------------------
-    // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the chain-dependent branches.
+    // ---- the next window: the slots cur, cur + 1, ... side by side, every proposal drawn from the chain's state -----------
+    // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the group-dependent branches.
     const double zi0 = zi, vi0 = vi;
     const int up = lane + 1 < 64 ? lane + 1 : 63;
     const double z_up = __shfl(zi0, up, 64), v_up = __shfl(vi0, up, 64);  // node i + 1 (death shifts the nodes down)
@@ -654,17 +670,22 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     };
     const double dl_cur = k == 1 ? 9999.9 : group_max((i >= 1 && i < k) ? zi0 : -INFINITY);
     const double zmin_cur = -group_max(i < k ? -zi0 : -INFINITY);  // the shallowest node: its velocity is the TOP layer's
-    int e = 0, s = cur, nact = 0;
-    int inv = 0;                 // proposals outside the prior since the last entry
-    int my_e = -1;               // lane a: the a-th evaluated entry of the window ...
-    int my_n0 = 0;               // ... and the prefix of the sorted sources that lies above everything it changes (one load from
-                                 // the depth histogram, issued as soon as the entry is known: it is waited for after the loop)
-    unsigned long long idx = ctr;
-    bool going = !eval && !fin && s < 2 * k;
-    while (__any(going)) {
+    const bool propose_on = !eval && !fin;
+    int nslots = 0;                     // slots the window covers
+    if (propose_on) {
+        nslots = 2 * k - cur;
+        nslots = nslots < 0 ? 0 : (nslots > D ? D : nslots);
+    }
+    int ebase = 0, abase = 0, invbits = 0;
+    int my_e[NR], my_a[NR], my_n0[NR];  // this group's entry of every round, its place among the evaluated ones, its prefix
+    bool my_ev[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = r * NG + g;       // this group's slot of the window
+        const int s = cur + j;
+        const bool on = propose_on && j < nslots;
         const int propose = s == 0 ? (int)PT_BD : (int)PT_MH;
         const int ivo = s >> 1, ipar = s & 1;
-        rng.index = idx;
         zi = zi0;
         vi = vi0;
         int moved_node = 0;     // death: the removed node; perturbation: the node; birth: the new node
@@ -672,11 +693,11 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         int qk = k;
         double lp = 0.0;
         bool have = false;
-        if (going) {
+        if (on) {
             if (propose == PT_BD) {
                 // birth / death, 1/3 each, none at the k limits (prjmh_temper_rf.f90:669-713)
                 if (p.kmin != p.kmax) {
-                    const double u = R::philox_uniform(rng);
+                    const double u = R::draw_uniform(rng, nsw, 0, R::DRAW_MOVE);
                     int move;
                     if (k == p.kmax)
                         move = (u <= 0.3333) ? 2 : 0;
@@ -685,8 +706,8 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                     else
                         move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
                     if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
-                        const double zn = (p.hmx - p.hmin) * R::philox_uniform(rng);
-                        const double vn = p.vmin + (p.vmax - p.vmin) * R::philox_uniform(rng);
+                        const double zn = (p.hmx - p.hmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_A);
+                        const double vn = p.vmin + (p.vmax - p.vmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_B);
                         if (i == k) {
                             zi = zn;
                             vi = vn;
@@ -697,7 +718,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                         moved_node = k;
                         zthr = zn;
                     } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
-                        int idel = 1 + (int)(R::philox_uniform(rng) * (k - 1));
+                        int idel = 1 + (int)(R::draw_uniform(rng, nsw, 0, R::DRAW_A) * (k - 1));
                         if (idel > k - 1)
                             idel = k - 1;
                         if (i >= idel && i + 1 < k) {
@@ -714,7 +735,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
             } else {
                 // perturbation of (node ivo, parameter ipar), Cauchy step of scale (max - min)/pertsdsc (:721-759, PROPOSAL :1405)
                 const double scale = (ipar == 0 ? (p.hmx - p.hmin) : (p.vmax - p.vmin)) / p.pertsdsc;
-                const double step = scale * tan(3.141592653589793 * (R::philox_uniform(rng) - 0.5));
+                const double step = scale * tan(3.141592653589793 * (R::draw_uniform(rng, nsw, s, R::DRAW_MOVE) - 0.5));
                 if (i == ivo) {
                     if (ipar == 0)
                         zi += step;
@@ -738,22 +759,22 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         const bool in = have && i < qk;
         bool bad = in && (vi < p.vmin || vi > p.vmax);
         bad = bad || (in && qk > 1 && i >= 1 && (zi < 0.0 || zi > p.hmx));
-        int r = 0;  // rank of this node in depth (stable)
-        for (int j = 0; j < K; ++j) {
-            const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
-            r += (in && j < qk && (zj < zi || (zj == zi && j < i))) ? 1 : 0;
+        int rk_ = 0;  // rank of this node in depth (stable)
+        for (int q = 0; q < K; ++q) {
+            const double zq = __shfl(zi, gbase + (q & (G - 1)), 64);
+            rk_ += (in && q < qk && (zq < zi || (zq == zi && q < i))) ? 1 : 0;
         }
         double prev = 0.0;  // the node above in depth; the rule measures the second node's spacing from 0
-        for (int j = 0; j < K; ++j) {
-            const double zj = __shfl(zi, gbase + (j & (G - 1)), 64);
-            const int rj = __shfl(r, gbase + (j & (G - 1)), 64);
-            if (j < qk && r >= 2 && rj == r - 1)
-                prev = zj;
+        for (int q = 0; q < K; ++q) {
+            const double zq = __shfl(zi, gbase + (q & (G - 1)), 64);
+            const int rq = __shfl(rk_, gbase + (q & (G - 1)), 64);
+            if (q < qk && rk_ >= 2 && rq == rk_ - 1)
+                prev = zq;
         }
-        bad = bad || (in && qk > 1 && r >= 1 && (zi - prev < p.hmin || zi > p.hmx));
+        bad = bad || (in && qk > 1 && rk_ >= 1 && (zi - prev < p.hmin || zi > p.hmx));
         // (see pt_step_group: a move that involves the shallowest node changes the model from the surface downwards)
         {
-            const int r_moved = __shfl(r, gbase + (moved_node & (G - 1)), 64);
+            const int r_moved = __shfl(rk_, gbase + (moved_node & (G - 1)), 64);
             const bool removed = propose == PT_BD && qk < k;
             const bool touches_top = have && ((moved_node < k && z_old_moved <= zmin_cur) || (!removed && r_moved == 0));
             if (touches_top)
@@ -763,110 +784,107 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         const double dl_new = qk == 1 ? 9999.9 : dl_all;
         const bool ok = have && (__ballot(bad) & gmask) == 0ull;
         const bool trivial = d.incremental && cache_ok && zthr > d.zmax_src && dl_cur > d.zmax_src && dl_new > d.zmax_src;
-        if (going) {
-            if (ok) {
-                // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision: row m0 + e
-                const int m = m0 + e;
-                double *Vr = d.V + (size_t)m * d.ld_model, *Dr = d.D + (size_t)m * d.ld_model;
-                int nl;
-                if (qk == 1) {
-                    if (lead) {
-                        Vr[0] = Vr[1] = vi;
-                        Dr[0] = 9999.9;
-                    }
-                    nl = 1;
-                } else {
-                    if (in) {
-                        Vr[r] = vi;
-                        if (r >= 1)
-                            Dr[r - 1] = zi;
-                    }
-                    nl = qk - 1;
-                }
-                if (in && i < K) {
-                    d.pz[(size_t)m * K + i] = zi;
-                    d.pv[(size_t)m * K + i] = vi;
-                }
-                if (!trivial && i == nact) {
-                    my_e = e;
-                    my_n0 = prefix_above(d, fmin(zthr, fmin(dl_cur, dl_new)));
-                }
+        // entries are numbered in slot order: this group's among the groups of the round (one bit per group)
+        const unsigned long long mok = __ballot(ok) & leads, mev = __ballot(ok && !trivial) & leads, minv = __ballot(have && !ok) & leads;
+        const unsigned long long below = (1ull << gbase) - 1ull;
+        const int e = ebase + __popcll(mok & below), av = abase + __popcll(mev & below);
+        my_e[r] = e;
+        my_a[r] = av;
+        my_ev[r] = ok && !trivial;
+        my_n0[r] = 0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+            if ((minv >> (q * G)) & 1ull)
+                invbits |= 1 << (r * NG + q);
+        if (ok) {
+            // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision: row m0 + e
+            const int m = m0 + e;
+            double *Vr = d.V + (size_t)m * d.ld_model, *Dr = d.D + (size_t)m * d.ld_model;
+            int nl;
+            if (qk == 1) {
                 if (lead) {
-                    d.pk[m] = qk;
-                    d.plp[m] = lp;
-                    d.pactive[m] = trivial ? 3 : 1;
-                    d.pslot[m] = s;
-                    d.pinv[m] = inv;
-                    d.pctr[m] = rng.index;
-                    d.NL[m] = trivial ? 0 : nl;  // (trivial: an inactive row -- nothing to evaluate)
-                    if (!trivial) {
-                        const int prow = d.nchains + (wbuf * d.nchains + c) * D + e;
-                        rtmi::PtInc *o = d.inc + m;
-                        o->zthr = zthr;
-                        o->dl1 = dl_cur;
-                        o->dl2 = dl_new;
-                        o->pending = pending;
-                        o->pend_idx = pend_idx;
-                        o->mover = nact == 0 ? 1 : 0;
-                        o->cur_row = c;
-                        o->prop_row = prow;
-                        rtmi::PtPend *pp = d.pinfo + (size_t)(wbuf * d.nchains + c) * D + e;  // should it be accepted
-                        pp->zthr = zthr;
-                        pp->dl1 = dl_cur;
-                        pp->dl2 = dl_new;
-                        pp->prop_row = prow;
-                        unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;   // the row's sums start from zero
-                        ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
-                        d.alist[m0 + nact] = e;
-                    }
+                    Vr[0] = Vr[1] = vi;
+                    Dr[0] = 9999.9;
                 }
-                nact += trivial ? 0 : 1;
-                inv = 0;
-                idx = rng.index + 1;  // (the acceptance draw)
-                ++e;
+                nl = 1;
             } else {
-                if (have)
-                    inv += propose == PT_BD ? 1 : 256;
-                idx = rng.index;
+                if (in) {
+                    Vr[rk_] = vi;
+                    if (rk_ >= 1)
+                        Dr[rk_ - 1] = zi;
+                }
+                nl = qk - 1;
             }
-            ++s;
-            going = e < D && s < 2 * k;
-        }
-    }
-    // rows beyond the window are inactive; every evaluated row learns how many workgroups it gets and which prefix of the
-    // sorted sources lies above everything its proposal changes
-    if (i < D) {
-        const int m = m0 + i;
-        if (i >= e)
-            d.NL[m] = 0;
-        if (eval)
-            ;  // (the rows of an evaluation were written by pt_pack_current_kernel)
-        else if (i < nact) {
-            const int n0 = my_n0;
-            int nw = d.gx_launch;                        // per-slot engine: every row has the batched launch's workgroups
-            if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its evaluated rows
-                nw = (wg_total - i + nact - 1) / nact;
-                nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
-            } else if (wg_total < 0) {                   // queue engine: tasks of about -wg_total loaded sources
-                const long long loaded = (long long)d.nsrc - (d.incremental ? n0 : 0), T = -(long long)wg_total;
-                nw = (int)((loaded + T - 1) / T);
-                nw = nw < 1 ? 1 : (nw > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw);
+            if (in && i < K) {
+                d.pz[(size_t)m * K + i] = zi;
+                d.pv[(size_t)m * K + i] = vi;
             }
-            d.rowwg[m0 + my_e] = nw;
-            d.inc[m0 + my_e].n0 = n0;
-            d.pinfo[(size_t)(wbuf * d.nchains + c) * D + my_e].n0 = n0;
+            if (!trivial && lead)
+                my_n0[r] = prefix_above(d, fmin(zthr, fmin(dl_cur, dl_new)));  // (waited for after the rounds)
+            if (lead) {
+                d.pk[m] = qk;
+                d.plp[m] = lp;
+                d.pactive[m] = trivial ? 3 : 1;
+                d.pslot[m] = s;
+                d.NL[m] = trivial ? 0 : nl;  // (trivial: an inactive row -- nothing to evaluate)
+                if (!trivial) {
+                    const int prow = d.nchains + (wbuf * d.nchains + c) * D + e;
+                    rtmi::PtInc *o = d.inc + m;
+                    o->zthr = zthr;
+                    o->dl1 = dl_cur;
+                    o->dl2 = dl_new;
+                    o->pending = pending;
+                    o->pend_idx = pend_idx;
+                    o->mover = av == 0 ? 1 : 0;
+                    o->cur_row = c;
+                    o->prop_row = prow;
+                    rtmi::PtPend *pp = d.pinfo + (size_t)(wbuf * d.nchains + c) * D + e;  // should it be accepted
+                    pp->zthr = zthr;
+                    pp->dl1 = dl_cur;
+                    pp->dl2 = dl_new;
+                    pp->prop_row = prow;
+                    unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;   // the row's sums start from zero
+                    ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
+                    d.alist[m0 + av] = e;
+                }
+            }
         }
+        ebase += __popcll(mok);
+        abase += __popcll(mev);
     }
-    if (lead && !eval) {
-        d.nwin[c] = fin ? -1 : e;
-        d.wend[c] = s;
-        d.wctr[c] = idx;
-        d.winv[c] = inv;
-        d.nact[c] = nact;
-    }
-    if (lead && eval) {
+    // every evaluated row learns how many workgroups it gets and which prefix of the sorted sources lies above everything its
+    // proposal changes; rows beyond the window are inactive
+    const int nact = abase;
+    if (!eval) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lead && my_ev[r]) {
+                const int n0 = my_n0[r];
+                int nw = d.gx_launch;                        // per-slot engine: every row has the batched launch's workgroups
+                if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its evaluated rows
+                    nw = (wg_total - my_a[r] + nact - 1) / nact;
+                    nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
+                } else if (wg_total < 0) {                   // queue engine: tasks of about -wg_total loaded sources
+                    const long long loaded = (long long)d.nsrc - (d.incremental ? n0 : 0), T = -(long long)wg_total;
+                    nw = (int)((loaded + T - 1) / T);
+                    nw = nw < 1 ? 1 : (nw > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw);
+                }
+                d.rowwg[m0 + my_e[r]] = nw;
+                d.inc[m0 + my_e[r]].n0 = n0;
+                d.pinfo[(size_t)(wbuf * d.nchains + c) * D + my_e[r]].n0 = n0;
+            }
+        if (g == 0 && i < D && i >= ebase)
+            d.NL[m0 + i] = 0;
+        if (lane == 0) {
+            d.nwin[c] = fin ? -1 : ebase;
+            d.wend[c] = cur + nslots;
+            d.winv[c] = invbits | (nslots << 8);
+            d.nact[c] = nact;
+        }
+    } else if (lane == 0) {
         d.nwin[c] = -1;
         d.nact[c] = 0;
+        d.walloc[c] = d.walloc[d.nchains + c] = 2 * k + 1;
     }
 }
 

@@ -79,6 +79,31 @@ RTMI_HD double philox_normal(Philox &p)
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
 
+// ---- the sampler's draws, INDEXED BY WHAT THEY ARE FOR ---------------------------------------------------------
+// A chain's draw is a pure function of (seed, stream, chain; sweep, slot, purpose): Philox counter word 1 = the number of
+// the sweep, word 0 = slot * 8 + purpose, slot = 0 birth/death, 2 ivo + ipar for the perturbation of (node ivo, parameter
+// ipar), SLOT_SIGMA for the sigma move.  No draw depends on how many draws were taken before it -- in particular not on
+// whether the proposals of earlier slots fell inside the prior -- so the proposals of ALL the slots of a window are known at
+// once and a group of lanes each can work them out side by side (rtmi_pt_dev.hpp::pt_step_spec).  [Rounds 1-3 took the
+// draws from a running position of the chain's stream; the laws are the same, the streams are not.]
+enum : int { DRAW_MOVE = 0, DRAW_A = 1, DRAW_B = 2, DRAW_ACCEPT = 3, DRAW_N1 = 4, DRAW_N2 = 5, SLOT_SIGMA = 255 };
+
+RTMI_HD double draw_uniform(Philox &p, uint64_t sweep, int slot, int purpose)
+{
+    p.index = (sweep << 32) | (uint64_t)(uint32_t)(slot * 8 + purpose);
+    return philox_uniform(p);
+}
+
+// Box-Muller from the two uniforms (slot, DRAW_N1), (slot, DRAW_N2), as philox_normal
+RTMI_HD double draw_normal(Philox &p, uint64_t sweep, int slot)
+{
+    double u1 = draw_uniform(p, sweep, slot, DRAW_N1);
+    const double u2 = draw_uniform(p, sweep, slot, DRAW_N2);
+    if (u1 < 1e-300)
+        u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
 // ---- prior, likelihood, bounds ---------------------------------------------------------------------------------
 RTMI_HD double log_pk(const rtmi_pt_prior &p, int k)  // Poisson prior on k (read_input.f90:78-81)
 {

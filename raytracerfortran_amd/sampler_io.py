@@ -99,13 +99,13 @@ def format_es(values, width: int, digits: int) -> str:
 
 
 def sample_row(logl: float, logpr: float, tcmp: float, nodes_sorted: np.ndarray, sd: float, nlmx: int,
-               acc_ratio: float = 0.0, iacc_bd: int = 0, irej_bd: int = 0, ic: int = 1, rank: int = 1) -> str:
+               acc_ratio: float = 0.0, iacc_bd: int = 0, irej_bd: int = 0, ic: int = 1, rank: int = 1, iacc_bds: int = 0) -> str:
     """One `<base>_voro_sample.txt` record (SAVESAMPLE, prjmh_temper_rf.f90:1870-1883, FORMAT(500ES18.8))."""
     voro = np.zeros(nlmx * 2)
     k = nodes_sorted.shape[0]
     voro[:2 * k] = nodes_sorted.reshape(-1)
     vals = [logl, logpr, tcmp, float(k)] + voro.tolist() + [sd, 0.0, 0.0, acc_ratio, float(iacc_bd), float(irej_bd),
-                                                            0.0, float(ic), float(rank)]
+                                                            float(iacc_bds), float(ic), float(rank)]   # SdRT, ArPar, ArParRT, ...
     return format_es(vals, 18, 8)
 
 
@@ -153,10 +153,21 @@ def run_from_files(directory: str, nsweeps: int, nchains: int = 8, seed: int = 1
     s = engine(prior, ev, ndata=obs.size, nchains_total=nchains, nptchains1=par["NPTCHAINS1"], dTlog=par["dTlog"],
                seed=seed)
     s.init_from_model(nodes, sd)
+    import time
+    t0 = time.perf_counter()
     samples = s.run(nsweeps, burnin=burnin, thin=par["ICHAINTHIN"])
+    tcmp = (time.perf_counter() - t0) / max(1, nsweeps)
+    # SAVESAMPLE's bookkeeping columns (prjmh_temper_rf.f90:1880-1883; names in raytracerR-export-data-to-MCMC.Rmd:135-146):
+    # logPr = the Poisson prior of k (read_input.f90:78-81), tcmp = seconds of computation per step (obj%tcmp, :453), acc_ratio =
+    # accepted / proposed perturbations, iacc_bd / irej_bd / iacc_bds = accepted and rejected birth-death moves and accepted
+    # sigma moves.  The reference keeps these counters per chain and writes their values at the time of the sample; the device
+    # sampler keeps them per handle, so every row carries the totals of the run (all local chains).
+    st = s.stats
+    acc_ratio = st["acc_mh"] / max(1, st["prop_mh"])
     with open(out_base + "_voro_sample.txt", "w") as f:
         for kk, nd, sdv, ll in samples:
-            f.write(sample_row(ll, 0.0, 0.0, nd, sdv, par["NLMX"]) + "\n")
+            f.write(sample_row(ll, prior.log_pk(int(kk)), tcmp, nd, sdv, par["NLMX"], acc_ratio=acc_ratio, iacc_bd=st["acc_bd"],
+                               irej_bd=st["prop_bd"] - st["acc_bd"], iacc_bds=st["acc_sd"], ic=1, rank=getattr(s, "rank", 0) + 1) + "\n")
     return {"samples": samples, "sampler": s, "parameters": par}
 
 

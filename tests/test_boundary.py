@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -149,7 +151,7 @@ def test_bench_timing_harness_two_ranks_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -117,9 +117,11 @@ def test_trans_dimensional_odds_match_the_evidence_ratio(small, beta):
 
 def test_config3_recovers_sigma_and_the_velocity_profile():
     """BASELINE config 3's problem (32 tempered chains, 1e4 sources of the generating 7-layer model + N(0, 0.016 s)), 6000
-    sweeps from a 2-layer start (the full-size run of profiles/config3_run.py takes 10 000): the T = 1 chain's sigma within 5 % of 0.016 s and its velocity at the middle of every
-    generating layer within 4 posterior standard deviations (+ 1 % of the value: the posterior std of a well-resolved layer is
-    a few m/s) of the truth."""
+    sweeps from a 2-layer start (the full-size run of profiles/config3_run.py takes 10 000): the T = 1 chain's sigma within
+    5 % of 0.016 s; its velocity in the middle of every generating layer that the sources sample from top to bottom
+    (1500 ... 3960 m; the sources lie between 1050 and 4200 m) within 4 posterior standard deviations + 1 % of the truth; and the
+    vertical travel time through the 1500 m above them -- all the data can say about those two layers: their velocities and
+    the interface between them trade off against each other -- within 0.5 %."""
     import torch
     import raytracerfortran_amd as rt
     from raytracerfortran_amd import synthetic as S
@@ -139,12 +141,19 @@ def test_config3_recovers_sigma_and_the_velocity_profile():
     assert len(samples) == 500
     sds = np.array([x[2] for x in samples])
     assert abs(sds.mean() - 0.016) < 0.05 * 0.016, sds.mean()
-    zq = np.array([500.0, 1250.0, 1750.0, 2250.0, 2900.0, 3600.0, 4100.0])   # the middle of every generating layer
+    zq = np.array([1750.0, 2250.0, 2900.0, 3600.0])            # the middle of the generating layers 3 ... 6
+    vtrue = np.array(S.TRUE_V)[2:6]
     vq = np.array([nodes[np.searchsorted(nodes[:, 0], zq, side="right") - 1, 1] for _, nodes, _, _ in samples])
-    # layers the data constrain: sources lie between 1050 and 4200 m, so every layer is crossed by rays
-    err = np.abs(vq.mean(0) - np.array(S.TRUE_V))
-    tol = 4.0 * vq.std(0) + 0.01 * np.array(S.TRUE_V)
-    print("sigma %.5f; v mean %s std %s" % (sds.mean(), vq.mean(0).round(1), vq.std(0).round(1)))
+    err = np.abs(vq.mean(0) - vtrue)
+    tol = 4.0 * vq.std(0) + 0.01 * vtrue
+    def t_top(nodes, zmax=1500.0):                             # vertical travel time from the surface to zmax
+        z = np.append(nodes[:, 0], np.inf)
+        return sum((min(z[i + 1], zmax) - z[i]) / nodes[i, 1] for i in range(nodes.shape[0]) if z[i] < zmax)
+    tts = np.array([t_top(nodes) for _, nodes, _, _ in samples])
+    tt_true = 1000.0 / 3100.0 + 500.0 / 2400.0
+    print("sigma %.5f; v mean %s std %s; vertical time to 1500 m %.5f +- %.5f (true %.5f)"
+          % (sds.mean(), vq.mean(0).round(1), vq.std(0).round(1), tts.mean(), tts.std(), tt_true))
     assert np.all(err < tol), (err, tol)
+    assert abs(tts.mean() - tt_true) < 0.005 * tt_true, (tts.mean(), tt_true)
     true_ll = T.gaussian_loglike(float(np.sum((obs - tt) ** 2)), nsrc, 0.016)
     assert np.median([x[3] for x in samples]) > true_ll - 40.0

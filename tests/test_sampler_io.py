@@ -92,6 +92,19 @@ def test_run_from_files_with_injected_likelihood(tmp_path, T1):
     rows = S.read_sample_file(str(tmp_path / "test_1_voro_sample.txt"), 10)
     assert len(rows) == len(r["samples"]) == 12  # ICHAINTHIN = 5, one chain at T = 1
     assert all(1 <= x["k"] <= 10 for x in rows)
+    # SAVESAMPLE's bookkeeping columns (prjmh_temper_rf.f90:1880-1883; the R notebook names them, Rmd:135-146): LogPrior, tcmp
+    # and, behind the 2 x NLMX node columns, SdRT, ArPar, ArParRT, acc_ratio, iacc_bd, irej_bd, iacc_bds, ic, rank
+    st = r["sampler"].stats
+    pr = r["sampler"].prior
+    for ln, x in zip(open(tmp_path / "test_1_voro_sample.txt"), rows):
+        t = np.array(ln.split(), dtype=float)
+        assert t.size == 4 + 2 * 10 + 9
+        assert abs(t[1] - pr.log_pk(x["k"])) < 1e-7 and t[2] > 0.0
+        tail = t[4 + 2 * 10:]
+        assert tail[1] == 0.0 and tail[2] == 0.0
+        assert abs(tail[3] - st["acc_mh"] / max(1, st["prop_mh"])) < 1e-7 and 0.0 < tail[3] <= 1.0
+        assert tail[4] == st["acc_bd"] and tail[5] == st["prop_bd"] - st["acc_bd"] and tail[6] == st["acc_sd"]
+        assert tail[7] == 1.0 and tail[8] == 1.0
 
 
 @pytest.mark.gpu

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from raytracerfortran_amd import tempering as T
 
 
@@ -128,7 +128,7 @@ def test_two_ranks_take_identical_swap_decisions_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_pt_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -251,7 +251,7 @@ def test_chains_sharded_over_two_ranks_native(kat):
     nodes = np.column_stack([[0.0] + m["depths"], m["vels"]]).tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_native_pt_worker, args=(r, 2, port, q, off, dep, obs, nodes)) for r in range(2)]
     for p in procs:
         p.start()
@@ -325,7 +325,7 @@ def test_swap_decide_two_ranks_identical_decisions_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_swap_decide_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
