@@ -7,6 +7,9 @@
 // if the GPU path cannot run, the call fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -219,6 +222,7 @@ int launch_batch(const double *d_vels, const double *d_depths, const int32_t *d_
             fa.part_stride = part_stride;
             fa.acc_atomic = acc_atomic;
             fa.d_pinfo = d_pinfo;
+            fa.count_words = nmodels * (part_stride > 0 ? part_stride : 1);
             if (d_inc && d_r2) {
                 fa.d_inc = d_inc;
                 fa.d_r2 = d_r2;
@@ -307,7 +311,7 @@ int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *
                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus, const void *ptdev,
                    size_t ptdev_bytes, const void *d_sweep_args, int nspec, unsigned int epoch, int parity, int nslots_k, hipStream_t stream,
                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
-                   int part_stride, const rtmi::PtPend *d_pinfo)
+                   int part_stride, const rtmi::PtPend *d_pinfo, int count_words)
 {
     const Tuning tn = tuning_snapshot();
     if (!batch_takes_fused(tn, nsrc) || !d_partial_x)
@@ -336,6 +340,7 @@ int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *
     fa.part_stride = part_stride;
     fa.acc_atomic = 1;
     fa.d_pinfo = d_pinfo;
+    fa.count_words = count_words > 0 ? count_words : 1;
     if (d_inc && d_r2) {
         fa.d_inc = d_inc;
         fa.d_r2 = d_r2;
@@ -347,56 +352,6 @@ int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *
         (void)hipGetLastError();  // not sticky: the caller falls back
         if (getenv("RTMI_PT_VERBOSE"))
             fprintf(stderr, "rtmi: speculative sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
-        return -1;
-    }
-    return RTMI_OK;
-}
-
-int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,
-                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus,
-                    const void *ptdev, size_t ptdev_bytes, const void *d_queue_args, int nspec, unsigned int fin_target, int task_src,
-                    hipStream_t stream,
-                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
-                    int part_stride, const rtmi::PtPend *d_pinfo)
-{
-    const Tuning tn = tuning_snapshot();
-    if (!batch_takes_fused(tn, nsrc) || !d_partial_x)
-        return -1;
-    int *d_status = nullptr;
-    int rc = status_word_for(stream, &d_status);
-    if (rc)
-        return rc;
-    rtmi::FusedArgs fa;
-    memset(&fa, 0, sizeof fa);
-    fa.d_vels = d_vels;
-    fa.d_depths = d_depths;
-    fa.d_nlayers = d_nlayers;
-    fa.ld_model = ld_model;
-    fa.refill_min = tn.refill_min;
-    fa.tail_group = tn.tail_group;
-    fa.retire_max = tn.retire_max;
-    fa.d_status = d_status;
-    fa.promote_age = tn.promote_age;
-    fa.allow_skip = 1;
-    fa.d_src_offset = d_src_offset;
-    fa.d_src_depth = d_src_depth;
-    fa.nsrc = nsrc;
-    fa.d_obs = d_obs;
-    fa.d_partial_x = d_partial_x;
-    fa.part_stride = part_stride;
-    fa.acc_atomic = 1;
-    fa.d_pinfo = d_pinfo;
-    if (d_inc && d_r2) {
-        fa.d_inc = d_inc;
-        fa.d_r2 = d_r2;
-        fa.d_inc_counts = d_inc_counts;
-    }
-    const hipError_t e = rtmi_launch_pt_queue(&fa, ptdev, ptdev_bytes, static_cast<const rtmi::PtQueueArgs *>(d_queue_args), nspec,
-                                              fin_target, max_nlayers, cus, tn.solve_waves, task_src, stream);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();  // not sticky: the caller falls back
-        if (getenv("RTMI_PT_VERBOSE"))
-            fprintf(stderr, "rtmi: queue sweep launch refused (%s): using the per-slot launches\n", hipGetErrorString(e));
         return -1;
     }
     return RTMI_OK;
@@ -668,7 +623,46 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
                                want_p ? dv + nm + 3 * n : nullptr, c.stream);
         if (rc)
             return rc;
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        // Completion: a launch plus an interrupt-driven hipStreamSynchronize costs more than the reference's whole call at its
+        // own example size (41 us against 28 us for NSrc = 20, round 3).  The stream writes a sequence number into a mapped
+        // pinned word right behind the kernel (a command-processor write, ordered after the kernel's completion and its
+        // release to system scope) and this thread spins on that word -- bounded: a call that takes longer than a few
+        // hundred microseconds sleeps in hipStreamSynchronize like before.  RTMI_DROPIN_SPIN=0 switches it off.
+        bool seen = false;
+        if (c.done_ok != 0) {
+            static const bool spin_on = !(getenv("RTMI_DROPIN_SPIN") && !strcmp(getenv("RTMI_DROPIN_SPIN"), "0"));
+            if (c.done_ok < 0) {
+                unsigned int *w = nullptr;
+                c.done_ok = (spin_on && hipHostMalloc((void **)&w, 64, hipHostMallocMapped) == hipSuccess) ? 1 : 0;
+                if (c.done_ok) {
+                    *w = 0u;
+                    c.h_done = w;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (c.done_ok == 1) {
+                const unsigned int seq = ++c.done_seq;
+                if (hipStreamWriteValue32(c.stream, (void *)c.h_done, seq, 0) == hipSuccess) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (int spins = 0;; ++spins) {
+                        if (*c.h_done == seq) {
+                            seen = true;
+                            break;
+                        }
+                        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400))
+                            break;
+                        __builtin_ia32_pause();
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                } else {
+                    (void)hipGetLastError();
+                    c.done_ok = 0;  // not available on this stack: the synchronise below, from now on
+                }
+            }
+        }
+        if (!seen)
+            HIP_TRY(hipStreamSynchronize(c.stream));
         if (int st = rtmi_device_status())
             return device_fault(st);
         memcpy(timeP, h + nm + 2 * n, n * sizeof(double));

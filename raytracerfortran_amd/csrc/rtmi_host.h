@@ -42,6 +42,11 @@ struct Context {
     size_t pin_cap = 0;
     double *h_small = nullptr;  // pinned, device-mapped buffer of the small-call path of dff_ / TraceRays
     size_t small_cap = 0;
+    // completion word of the small-call path: the stream writes a sequence number into it behind the kernel
+    // (hipStreamWriteValue32) and the host spins on it instead of sleeping in hipStreamSynchronize
+    volatile unsigned int *h_done = nullptr;
+    unsigned int done_seq = 0;
+    int done_ok = -1;           // -1 untried, 0 the stream memory operation is not available: hipStreamSynchronize, 1 in use
 };
 Context &ctx();
 int ensure_ready_locked(Context &c);
@@ -99,16 +104,7 @@ int launch_pt_prop(const double *d_vels, const double *d_depths, const int32_t *
                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus, const void *ptdev,
                    size_t ptdev_bytes, const void *d_sweep_args, int nspec, unsigned int epoch, int parity, int nslots_k, hipStream_t stream,
                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
-                   int part_stride, const rtmi::PtPend *d_pinfo);
-// The speculative sweep over a task queue (rtmi_kernels.hip::pt_sweep_queue_kernel): an ordinary launch of one workgroup per
-// CU.  Non-zero = not available (the plain kernel path is selected): use the per-slot launches.
-int launch_pt_queue(const double *d_vels, const double *d_depths, const int32_t *d_nlayers, int ld_model, int max_nlayers,
-                    const double *d_src_offset, const double *d_src_depth, int64_t nsrc, const double *d_obs, int cus,
-                    const void *ptdev, size_t ptdev_bytes, const void *d_queue_args, int nspec, unsigned int fin_target, int task_src,
-                    hipStream_t stream,
-                    const rtmi::PtInc *d_inc, double *d_r2, unsigned long long *d_inc_counts, unsigned long long *d_partial_x,
-                    int part_stride, const rtmi::PtPend *d_pinfo);
-
+                   int part_stride, const rtmi::PtPend *d_pinfo, int count_words);
 }  // namespace rtmi_host
 
 #endif

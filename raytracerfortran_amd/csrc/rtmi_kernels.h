@@ -111,6 +111,7 @@ struct FusedArgsT {
     int acc_atomic;                // the sampler's form: a row's workgroups ADD their exact sums into d_partial_x[m][0] (three limbs of 48
                                    // bits + the flags, 64-bit atomics: integer addition commutes) instead of writing a slot each
     const PtPend *d_pinfo;         // records of accepted proposals (PtInc::pend_idx) or NULL
+    int count_words;               // with acc_atomic: pairs of words d_inc_counts holds (one pair per workgroup of the launch, modulo this)
     unsigned long long *d_stamps;  // diagnostic clocks [gridDim.x][RTMI_STAMPS_PER_WG] or NULL
     int diag_fine;                 // with d_stamps: also the per-trip section clocks and counters
 };
@@ -131,31 +132,10 @@ struct PtSweepArgs {
     int nspec;             // > 0: the speculative step (rtmi_pt_dev.hpp::pt_step_spec) with this many model rows per chain; a
                            // chain runs passes until its sweep is complete (nslots_k only bounds them), `epoch` is a tag of
                            // the sweep (the passes of a sweep count from it, at most 4096)
+    unsigned long long *stats;  // NULL, or [8] diagnostic sums (RTMI_PT_QSTATS): ticks in the likelihood, in steps, waiting; passes
     int *walloc;           // speculative form: [2][nchains] weights (slots of the chain's sweep) by which the launch's workgroups
     int parity;            // are dealt to the chains: read from walloc[parity], rewritten for the next sweep in walloc[1 - parity]
 };
-
-// Arguments of the tempering sampler's sweep as a persistent kernel over a TASK QUEUE (pt_sweep_queue_kernel): workgroups are
-// not bound to chains.  A task = one share (sub of nw) of one model row's sources; the step of a chain is taken by whichever
-// workgroup finishes the last task of the chain's window, and publishes the next window's tasks.
-#define RTMI_PTQ_RINGS 2  // priority classes: ring 0 is served first
-struct PtQueueArgs {
-    unsigned long long *slots;  // [RTMI_PTQ_RINGS][qmask + 1] (ticket + 1) << 32 | task word, published with release
-    unsigned int *ctl;          // ring r: tail (tickets produced) at ctl[32 r], head (tickets claimed) at ctl[32 r + 16]; never reset
-    unsigned int *pendcnt;      // [nchains] tasks of the chain's window that are still out
-    unsigned int *rem;          // [nchains] proposal slots the chain still has to decide in this sweep (priority: longest first)
-    unsigned int *nfinished;    // chains whose sweep is complete, counted over all launches (a launch is told where its sweep ends)
-    unsigned int *abort_;       // [1] set when a bounded wait ran out: every workgroup leaves at its next wait
-    unsigned int qmask;         // ring size - 1 (power of two, larger than the tasks that can be out at once)
-    int nchains;
-    int nspec;                  // model rows per chain (rtmi_pt_dev.hpp::pt_step_spec)
-    int task_fine, task_coarse; // sources per task when workgroups are idle / when the rings are backed up
-    unsigned long long *stats;  // NULL, or [8] diagnostic sums over workgroups and launches: ticks (100 MHz) in tasks, in steps, waiting
-                                // for a task; tasks; steps; workgroup lifetimes (RTMI_PT_QSTATS)
-};
-#define RTMI_PTQ_POISON 0x80000000u   // ptq_take: the sweep is complete (or aborted), the workgroup leaves
-#define RTMI_PTQ_WORD(chain, e, sub, nw) ((unsigned int)(chain) | ((unsigned int)(e) << 16) | ((unsigned int)(sub) << 19) | ((unsigned int)((nw) - 1) << 25))
-#define RTMI_PTQ_MAX_NW 64            // shares per row (6 bits)
 
 // Arguments of the single-precision fast forward model (rtmi_f32fast.hip).  Sorted interfaces, positive velocities.
 #define RTMI_F32FAST_MAX_NL 63
@@ -191,12 +171,6 @@ hipError_t rtmi_launch_fused(const rtmi::FusedArgs *args, int nmodels, int max_n
 hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
                                 const rtmi::PtSweepArgs *w, int nchains, int max_nlayers, int num_cus,
                                 int waves_per_simd, hipStream_t stream);
-// The queue form of the sweep: an ordinary launch of one workgroup per CU (no co-residency needed: a workgroup only ever
-// waits for a ticket whose task running workgroups will produce).  d_q: DEVICE copy of the queue's (constant) words;
-// fin_target: value of *nfinished at which this launch's sweep is complete; task_src: sources per task the LDS is sized for.
-hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtQueueArgs *d_q,
-                                int nspec, unsigned int fin_target, int max_nlayers, int num_cus, int waves_per_simd, int task_src,
-                                hipStream_t stream);
 // The speculative sweep with the launch's workgroups dealt to the chains in proportion to their slots (pt_sweep_prop_kernel):
 // cooperative launch of one workgroup per CU.  d_w: DEVICE copy of the constant words (flag, count, abort_, walloc, nchains,
 // nspec); epoch (tag of the sweep), parity (which half of walloc to read) and nslots_k (bound of the passes) per launch.

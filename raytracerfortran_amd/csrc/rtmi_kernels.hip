@@ -1253,10 +1253,12 @@ __device__ __forceinline__ void fused_body(FusedArgsT<T> a, const int m, const i
                 o[3] = 0ull;
             }
             if (counting) {
-                if (a.acc_atomic) {  // (a row's shares are not bounded by pstride here)
-                    unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride);
-                    __hip_atomic_fetch_add(oc + 0, tr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(oc + 1, ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.acc_atomic) {
+                    // (a row's shares are not bounded by pstride here: every workgroup of the LAUNCH owns a pair of words -- the
+                    // launches of a handle are stream-ordered, so plain additions do)
+                    unsigned long long *oc = a.d_inc_counts + 2 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) % a.count_words);
+                    oc[0] += tr;
+                    oc[1] += ca;
                 } else {
                     unsigned long long *oc = a.d_inc_counts + 2 * ((int64_t)m * pstride + bx);
                     oc[0] += tr;
@@ -1396,6 +1398,10 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
         W += wc;
     }
     const long long R = nwg - nchains;
+    // consecutive blockIdx values go to consecutive XCDs (8 of them, an L2 each): the layout is made over the workgroups in
+    // XCD-major order, so that a chain's workgroups -- which pass model rows, residual rows and sums to each other every pass
+    // -- sit on one XCD where its share allows
+    const long long vb = (nwg & 7) == 0 ? (long long)(blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : (long long)blockIdx.x;
     long long carry = 0;
     for (int c0 = 0; c0 < nchains; c0 += 64) {
         const int c = c0 + lane;
@@ -1411,9 +1417,9 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
         const long long P = carry + incl - wc;
         const long long first = c + (R * P) / W;
         const long long next = c + 1 < nchains ? (c + 1) + (R * (P + wc)) / W : nwg;
-        if (c < nchains && (long long)blockIdx.x >= first && (long long)blockIdx.x < next) {
+        if (c < nchains && vb >= first && vb < next) {
             ctl[PROP_CHAIN] = c;
-            ctl[PROP_ROW] = (int)((long long)blockIdx.x - first);
+            ctl[PROP_ROW] = (int)(vb - first);
             ctl[PROP_GX] = (int)(next - first);
             ctl[PROP_BASE] = (int)__hip_atomic_load(wp->count + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1476,16 +1482,32 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
     using namespace rtmi_pt_dev;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     volatile int *ctl = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(lds_raw) + lds_ctl);
+    // (diagnostic, RTMI_PT_QSTATS: thread 0 keeps 64-bit sums of 100 MHz ticks behind the control words: [0] in the likelihood,
+    // [1] in steps, [2] waiting for the chain's flag or arrivals, [3] passes, [4] steps' passes, [5] start)
+    volatile unsigned long long *dg = reinterpret_cast<volatile unsigned long long *>(reinterpret_cast<char *>(lds_raw) + lds_ctl + 4 * PROP_WORDS);
+    const bool diag = wp->stats != nullptr;
+    if (diag && threadIdx.x == 0) {
+        dg[0] = dg[1] = dg[2] = dg[3] = dg[4] = 0ull;
+        dg[5] = __builtin_amdgcn_s_memrealtime();
+    }
     if (threadIdx.x < 64)
         prop_layout(wp, parity, ctl);
     __syncthreads();
 #pragma unroll 1
     for (int pass = 0; pass <= max_pass; ++pass) {
+        if (diag && threadIdx.x == 0)
+            dg[6] = __builtin_amdgcn_s_memrealtime();
         if (ctl[PROP_ROW] == 0) {
             if (threadIdx.x < 64)
                 prop_lead(dp, wp, ctl, pass, epoch, parity);
+            if (diag && threadIdx.x == 0) {
+                dg[1] += __builtin_amdgcn_s_memrealtime() - dg[6];
+                dg[4] += 1ull;
+            }
         } else if (threadIdx.x == 0) {
             ctl[PROP_GO] = pt_wait_reached(wp->flag + ctl[PROP_CHAIN], epoch + (unsigned int)pass + 1u, wp->abort_, a.d_status) ? 1 : 0;
+            if (diag)
+                dg[2] += __builtin_amdgcn_s_memrealtime() - dg[6];
         }
         __syncthreads();
         if (ctl[PROP_ROW] != 0 && !ctl[PROP_GO])
@@ -1495,8 +1517,20 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
         __builtin_amdgcn_s_dcache_inv();
         __syncthreads();
         const int nact = ctl[PROP_NACT];
-        if (nact <= 0)
-            return;  // the sweep of this chain is complete
+        if (nact <= 0) {  // the sweep of this chain is complete
+            if (diag && threadIdx.x == 0) {
+                unsigned long long *st = wp->stats;
+                __hip_atomic_fetch_add(st + 0, dg[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 1, dg[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 2, dg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 3, dg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 4, dg[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(st + 5, __builtin_amdgcn_s_memrealtime() - dg[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        if (diag && threadIdx.x == 0)
+            dg[6] = __builtin_amdgcn_s_memrealtime();
         {
             // enough workgroups: this one is share row / nact of ceil((gx - a) / nact) of the a-th row, a = row mod nact;
             // fewer workgroups than rows: it takes the rows row, row + gx, ... each on its own.  (One call site: the body is
@@ -1512,8 +1546,17 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
                 __syncthreads();
             }
         }
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
+            if (diag) {
+                const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+                dg[0] += t1 - dg[6];
+                dg[3] += 1ull;
+                dg[6] = t1;
+            }
             prop_arrive(wp, ctl, pass, a.d_status);
+            if (diag)
+                dg[2] += __builtin_amdgcn_s_memrealtime() - dg[6];
+        }
         __syncthreads();
         if (ctl[PROP_ROW] == 0) {
             if (!ctl[PROP_GO])
@@ -1524,282 +1567,6 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
     // never expected: a chain that is not complete after 2 k + 2 passes
     if (threadIdx.x == 0 && a.d_status)
         atomicOr(a.d_status, 16);
-}
-
-// ---- the speculative sweep over a TASK QUEUE ------------------------------------------------------------------------
-// With the speculative step (rtmi_pt_dev.hpp::pt_step_spec) a pass of a chain -- up to nspec model rows side by side -- is as
-// much work as the machine's share of a chain can take, and what is left on the table is the IMBALANCE between chains: a
-// sweep ends when the chain with the most nodes (most slots) has run its last pass, and workgroups bound to chains that were
-// done early idle for the rest of it.  Here no workgroup belongs to a chain:
-//   task   one share (sub of nw) of the sources of one model row: fused_body(row, sub, nw).  The sums are exact integers and
-//          a row's workgroups add theirs into the row's accumulator, so into how many shares a row is cut decides nothing.
-//   rings  task words in HBM, one ring per priority class.  A producer reserves tickets (atomic add on the ring's tail) and
-//          publishes each slot as (ticket + 1) << 32 | word with release; a consumer claims the next ticket of the first ring
-//          that has one (compare-and-swap on its head) and reads exactly that slot.  Tickets only grow, from launch to launch.
-//   order  LONGEST CHAIN FIRST: what bounds a sweep is the chain with the most slots left (its passes are sequential), so a
-//          chain within one window of the largest number of slots still to decide publishes to ring 0, the others to ring 1.
-//   size   a row is cut into tasks of task_fine sources while workgroups are idle (no backlog in the rings), of task_coarse
-//          sources when the rings are backed up (fewer, larger tasks: less of the per-task table staging).
-//   step   a chain's window is complete when its counter of outstanding tasks falls to zero: the workgroup that takes it
-//          there takes the chain's step at once -- decisions of the window, sigma move, next window (pt_step_spec) -- and
-//          publishes the next window's tasks; a window without tasks (every proposal below the deepest source) is stepped
-//          over on the spot.  The first step of every chain is taken at the start of the kernel.
-//   end    a workgroup that finds no task leaves once every chain's sweep is complete (a counter of finished chains).
-// A workgroup never waits for anything but a slot it has claimed after its ticket was reserved, so no co-residency is
-// needed: the launch is an ordinary one.  Every wait is bounded all the same (abort word + bit 16 of the fault word).
-// How a workgroup comes by its next task.  Ring 0 is a TICKET ring: a claim is one atomic add on its head and always
-// succeeds; a workgroup without work holds a ticket and polls the slot that belongs to it alone -- two hundred idle workgroups
-// do not touch one shared word (a compare-and-swap design, in which every idle workgroup watches head and tail, was measured:
-// each publication set off a storm of failed swaps on one address that stalled every other atomic of the kernel, 0.84 -> 3.4
-// ms per sweep).  Ring 1 holds what the low-priority chains publish while the machine is backed up; it is looked at only by
-// a workgroup that has just finished a task and finds ring 0 without a backlog, and claimed by compare-and-swap (few
-// contenders, never a waiter).  The end of the sweep comes as one poison per workgroup through ring 0.
-__device__ __noinline__ unsigned int ptq_take(const PtQueueArgs *qp, unsigned int fin_target, int *d_status)
-{
-    const PtQueueArgs q = *qp;
-    (void)fin_target;
-    unsigned int *tail0 = q.ctl, *head0 = q.ctl + 16, *tail1 = q.ctl + 32, *head1 = q.ctl + 48;
-    unsigned long long *slot = nullptr;
-    unsigned int want = 0;
-    // ring 1, if ring 0 has no backlog
-    if ((int)(__hip_atomic_load(tail0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-              __hip_atomic_load(head0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
-        unsigned int h = __hip_atomic_load(head1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll 1
-        for (int tries = 0; tries < 64; ++tries) {
-            const unsigned int t = __hip_atomic_load(tail1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int)(t - h) <= 0)
-                break;
-            if (__hip_atomic_compare_exchange_strong(head1, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                slot = q.slots + (size_t)(q.qmask + 1u) + (h & q.qmask);  // (its slot is filled right after the reservation we saw)
-                want = h + 1u;
-                break;
-            }
-        }
-    }
-    if (!slot) {
-        const unsigned int t = __hip_atomic_fetch_add(head0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        slot = q.slots + (t & q.qmask);
-        want = t + 1u;
-    }
-    int polls = 0;
-#pragma unroll 1
-    for (;;) {
-        // relaxed polls (an acquire per poll would invalidate the caches under the workgroups that are computing)
-        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned int)(v >> 32) == want) {
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // hipcc: agent scope
-            return (unsigned int)v;
-        }
-        if (__hip_atomic_load(q.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-            return RTMI_PTQ_POISON;
-        __builtin_amdgcn_s_sleep(8);
-        if (++polls > (1 << 23)) {  // seconds: never expected
-            __hip_atomic_store(q.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d_status)
-                atomicOr(d_status, 16);
-            return RTMI_PTQ_POISON;
-        }
-    }
-}
-
-// The chain's step(s) and what follows from them, by wave 0 of the calling workgroup (all 64 lanes call).  Real calls (this
-// one and ptq_take), with the queue's words read from memory: the kernel around them is the likelihood body at its register
-// limit, and everything that is inlined next to it is paid for in spills inside its loops.
-__device__ __noinline__ void ptq_step_and_publish(const rtmi_pt_dev::PtDev *dp, const PtQueueArgs *qp, int chain, int begin,
-                                                  int nwg, unsigned int fin_target, int *d_status)
-{
-    const PtQueueArgs q = *qp;
-    const int lane = threadIdx.x & 63;
-    // how the rings stand: tasks published and not yet claimed
-    int backlog = 0;
-#pragma unroll
-    for (int r = 0; r < RTMI_PTQ_RINGS; ++r)
-        backlog += (int)(__hip_atomic_load(q.ctl + 32 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                         __hip_atomic_load(q.ctl + 32 * r + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int task_src = backlog <= 0 ? q.task_fine : (backlog < nwg / 2 ? (q.task_fine + q.task_coarse) / 2 : q.task_coarse);
-    int fin_ = 0, nact_ = 0, guard = 0;
-#pragma unroll 1
-    for (;;) {
-        pt_step_spec_call(dp, chain, begin, -task_src);
-        __threadfence();                  // the rows are out before the tasks; and this workgroup (one L1) reads them afresh, too
-        __builtin_amdgcn_s_dcache_inv();  // ... the chain's words are wave-uniform: scalar loads
-        begin = 0;
-        fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fin_ || nact_ > 0)
-            break;
-        if (++guard > 4 * RTMI_PT_MAX_K) {  // never expected: a chain that neither proposes nor finishes
-            if (lane == 0 && d_status)
-                atomicOr(d_status, 16);
-            fin_ = 1;  // count it as complete so that the launch ends
-            break;
-        }
-    }
-    const int D = q.nspec;
-    if (fin_) {
-        unsigned int done = 0;
-        if (lane == 0) {
-            __hip_atomic_store(q.rem + chain, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            done = __hip_atomic_fetch_add(q.nfinished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        }
-        done = (unsigned int)__builtin_amdgcn_readfirstlane((int)done);
-        if (done == fin_target) {
-            // the sweep is complete: one poison per workgroup of the launch, through the ticket ring
-            unsigned int base = 0;
-            if (lane == 0)
-                base = __hip_atomic_fetch_add(q.ctl, (unsigned int)nwg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            for (int i = lane; i < nwg; i += 64) {
-                const unsigned int t = base + (unsigned int)i;
-                __hip_atomic_store(q.slots + (t & q.qmask), ((unsigned long long)(t + 1u) << 32) | RTMI_PTQ_POISON, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-    // priority: slots this chain still has to decide against the most any chain has
-    const int k_ = __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int cur_ = __hip_atomic_load(dp->cur + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int myrem = 2 * k_ - cur_ > 0 ? 2 * k_ - cur_ : 0;
-    if (lane == 0)
-        __hip_atomic_store(q.rem + chain, (unsigned int)myrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int gmax = myrem;
-    for (int c0 = 0; c0 < q.nchains; c0 += 64) {
-        const int c = c0 + lane;
-        const int r_ = c < q.nchains ? (int)__hip_atomic_load(q.rem + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        gmax = max(gmax, wave_max_i32(r_));
-    }
-    // ring 1 only for a chain that is not among the longest AND while ring 0 is backed up (without a backlog the idle
-    // workgroups are waiting on ring-0 tickets, and whatever is published goes to them)
-    const int backlog0 = (int)(__hip_atomic_load(q.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                               __hip_atomic_load(q.ctl + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int ring = (myrem + D >= gmax || backlog0 <= 0) ? 0 : 1;
-    // the window's tasks: row alist[a] in rowwg shares, a < nact (<= PT_SPEC_MAX rows)
-    int e_of[PT_SPEC_MAX], nw_of[PT_SPEC_MAX];
-    int ntask = 0;
-#pragma unroll
-    for (int a_ = 0; a_ < PT_SPEC_MAX; ++a_) {
-        e_of[a_] = 0;
-        nw_of[a_] = 0;
-        if (a_ < nact_) {
-            e_of[a_] = dp->alist[chain * D + a_];
-            nw_of[a_] = dp->rowwg[chain * D + e_of[a_]];
-            ntask += nw_of[a_];
-        }
-    }
-    unsigned int base = 0;
-    if (lane == 0) {
-        __hip_atomic_store(q.pendcnt + chain, (unsigned int)ntask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = __hip_atomic_fetch_add(q.ctl + 32 * ring, (unsigned int)ntask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    unsigned long long *slots = q.slots + (size_t)ring * (q.qmask + 1u);
-    for (int i = lane; i < ntask; i += 64) {
-        int r = i, a_sel = 0;
-#pragma unroll
-        for (int a_ = 0; a_ < PT_SPEC_MAX - 1; ++a_)
-            if (a_sel == a_ && r >= nw_of[a_]) {
-                r -= nw_of[a_];
-                a_sel = a_ + 1;
-            }
-        int e_sel = 0, nw_sel = 1;
-#pragma unroll
-        for (int a_ = 0; a_ < PT_SPEC_MAX; ++a_)
-            if (a_ == a_sel) {
-                e_sel = e_of[a_];
-                nw_sel = nw_of[a_];
-            }
-        const unsigned int t = base + (unsigned int)i;
-        __hip_atomic_store(slots + (t & q.qmask), ((unsigned long long)(t + 1u) << 32) | RTMI_PTQ_WORD(chain, e_sel, r, nw_sel),
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <int TF>
-__global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_queue_kernel(FusedArgsT<double> a, const rtmi_pt_dev::PtDev *dp, const PtQueueArgs *qp,
-                                                                              unsigned int fin_target, int lds_ctl)
-{
-    using namespace rtmi_pt_dev;
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    int *const d_status = a.d_status;
-    // past the likelihood's LDS: [0] task word, [1] take the chain's step; then (diagnostic, thread 0 only) 64-bit sums of
-    // ticks in tasks / steps / waits and counts of tasks / steps
-    volatile unsigned int *ctl = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(lds_raw) + lds_ctl);
-    volatile unsigned long long *dg = reinterpret_cast<volatile unsigned long long *>(reinterpret_cast<char *>(lds_raw) + lds_ctl + 16);
-    const bool diag = qp->stats != nullptr;  // wave-uniform
-    const int nwg = gridDim.x;
-    if (diag && threadIdx.x == 0) {
-        dg[0] = dg[1] = dg[2] = dg[3] = dg[4] = 0ull;
-        dg[5] = __builtin_amdgcn_s_memrealtime();
-    }
-    // the first step of every chain
-    if (threadIdx.x < 64) {
-        const int nchains = qp->nchains;
-#pragma unroll 1
-        for (int c = blockIdx.x; c < nchains; c += nwg) {
-            const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            ptq_step_and_publish(dp, qp, c, 1, nwg, fin_target, d_status);
-            if (diag && threadIdx.x == 0) {
-                dg[1] += __builtin_amdgcn_s_memrealtime() - t0;
-                dg[4] += 1ull;
-            }
-        }
-    }
-#pragma unroll 1
-    for (;;) {
-        __syncthreads();  // (ctl is free; LDS of the task before is free)
-        if (threadIdx.x == 0) {
-            const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            ctl[0] = ptq_take(qp, fin_target, d_status);
-            if (diag) {
-                const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-                dg[2] += t1 - t0;
-                dg[6] = t1;  // the task starts
-            }
-        }
-        __syncthreads();
-        const unsigned int word = ctl[0];
-        if (word & RTMI_PTQ_POISON) {
-            if (diag && threadIdx.x == 0) {
-                unsigned long long *st = qp->stats;
-                __hip_atomic_fetch_add(st + 0, dg[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 1, dg[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 2, dg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 3, dg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 4, dg[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 5, __builtin_amdgcn_s_memrealtime() - dg[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        __builtin_amdgcn_s_dcache_inv();
-        const int chain = (int)(word & 0xFFFFu), e = (int)((word >> 16) & 7u), sub = (int)((word >> 19) & 63u), nw = (int)((word >> 25) & 63u) + 1;
-        fused_body<double, false, false, true, false, TF, true, true>(a, chain * qp->nspec + e, sub, nw, reinterpret_cast<double *>(lds_raw));
-        __syncthreads();  // the task's sum is written (thread 0), LDS is free again
-        if (threadIdx.x == 0) {
-            __threadfence();
-            const unsigned int before = __hip_atomic_fetch_sub(qp->pendcnt + chain, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            ctl[1] = before == 1u ? 1u : 0u;
-            if (before == 1u)
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            if (diag) {
-                dg[0] += __builtin_amdgcn_s_memrealtime() - dg[6];
-                dg[3] += 1ull;
-            }
-        }
-        __syncthreads();
-        if (ctl[1]) {  // this was the last task of the chain's window: its step is ours
-            __builtin_amdgcn_s_dcache_inv();
-            if (threadIdx.x < 64) {
-                const unsigned long long t0 = diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                ptq_step_and_publish(dp, qp, chain, 0, nwg, fin_target, d_status);
-                if (diag && threadIdx.x == 0) {
-                    dg[1] += __builtin_amdgcn_s_memrealtime() - t0;
-                    dg[4] += 1ull;
-                }
-            }
-        }
-    }
 }
 
 template <int TF, bool INCR>
@@ -2335,7 +2102,7 @@ extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const voi
     int threads = 0;
     (void)rtmi_fused_geometry(a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads, &a.slots, &lds_bytes);
     int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
-    lds_bytes = (size_t)lds_ctl + 4 * PROP_WORDS;
+    lds_bytes = (size_t)lds_ctl + 4 * PROP_WORDS + 64;  // + the kernel's control words and its diagnostic sums
     if (lds_bytes > 160 * 1024 || threads < 64)
         return hipErrorInvalidValue;
     if (a.rows == 2)
@@ -2347,50 +2114,6 @@ extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const voi
     int max_pass = 2 * nslots_k + 2;  // a pass retires at least one slot of the chain
     void *kargs[7] = {&a, &dp, &d_w, &epoch, &parity, &max_pass, &lds_ctl};
     return hipLaunchCooperativeKernel(fn, dim3((unsigned)num_cus), dim3((unsigned)threads), kargs, lds_bytes, stream);
-}
-
-extern "C" hipError_t rtmi_launch_pt_queue(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes,
-                                           const rtmi::PtQueueArgs *d_q, int nspec, unsigned int fin_target, int max_nlayers,
-                                           int num_cus, int waves_per_simd, int task_src, hipStream_t stream)
-{
-    using namespace rtmi;
-    using rtmi_pt_dev::PtDev;
-    if (!args || !ptdev || !d_q || ptdev_bytes != sizeof(PtDev) || !args->d_obs || !args->d_nlayers || args->d_timeP ||
-        !args->d_partial_x || nspec < 1 || nspec > PT_SPEC_MAX || task_src < 64)
-        return hipErrorInvalidValue;
-    {
-        const hipError_t e = prepare_fused_t<double>();
-        if (e != hipSuccess)
-            return e;
-    }
-    FusedArgs a = *args;
-    const PtDev *dp = static_cast<const PtDev *>(ptdev);  // a DEVICE copy of the handle's view
-    a.max_nlayers = max_nlayers;
-    a.rows = RTMI_TABLE_FORM(max_nlayers);
-    a.skiptab = max_nlayers <= RTMI_SKIP_MAX_NL ? 1 : 0;
-    a.refill_min = a.refill_min < 1 ? 1 : (a.refill_min > 64 ? 64 : a.refill_min);
-    // one workgroup per CU; its record area holds one task (task_src sources + a chunk of rounding) in one round
-    size_t lds_bytes = 0;
-    int threads = 0;
-    const int64_t task = ((int64_t)task_src + 63) / 64 * 64 + 64;
-    (void)rtmi_fused_geometry(task < a.nsrc ? task : a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads,
-                              &a.slots, &lds_bytes);
-    const int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
-    lds_bytes = (size_t)lds_ctl + 16 + 64;  // + the kernel's control words and its diagnostic sums
-    if (lds_bytes > 160 * 1024 || threads < 64)
-        return hipErrorInvalidValue;
-    if (a.rows == 2)
-        a.rows = 0;  // (as in rtmi_launch_pt_sweep: form 0 with the body inlined into a loop)
-    const void *fn = a.rows == 1 ? reinterpret_cast<const void *>(&pt_sweep_queue_kernel<1>) : reinterpret_cast<const void *>(&pt_sweep_queue_kernel<0>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess)
-        return e;
-    if (a.rows == 1)
-        hipLaunchKernelGGL((pt_sweep_queue_kernel<1>), dim3((unsigned)num_cus), dim3((unsigned)threads), lds_bytes, stream, a, dp, d_q, fin_target, lds_ctl);
-    else
-        hipLaunchKernelGGL((pt_sweep_queue_kernel<0>), dim3((unsigned)num_cus), dim3((unsigned)threads), lds_bytes, stream, a, dp, d_q,
-                           fin_target, lds_ctl);
-    return hipGetLastError();
 }
 
 extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers,

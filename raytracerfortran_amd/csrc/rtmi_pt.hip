@@ -54,8 +54,8 @@ __device__ __forceinline__ void load_nodes(const double *src, double *dst, int k
 // Working arrays of pt_pack_current_kernel (one thread per chain) live in LDS, not in private (scratch) memory: the
 // rules index them dynamically.  Layout: thread t owns [t * stride, (t + 1) * stride).
 #define PT_BLOCK 64
-#ifndef RTMI_PT_SPECULATE_DEFAULT
-#define RTMI_PT_SPECULATE_DEFAULT 4  // model rows per chain of the speculative step (RTMI_PT_SPECULATE overrides; 0 = one-at-a-time step)
+#ifndef RTMI_PT_SPECULATE_MAX_SHARE
+#define RTMI_PT_SPECULATE_MAX_SHARE 4096  // sources per workgroup of a chain up to which the handle speculates by default (RTMI_PT_SPECULATE overrides)
 #endif
 
 // pt_step_kernel: the sampler's step (rtmi_pt_dev.hpp::pt_step_group) for every chain, one group of G lanes per chain.
@@ -252,15 +252,7 @@ struct rtmi_pt {
     unsigned long long *d_spec_u64 = nullptr;  // wctr (per chain), pctr (per row)
     double *d_pend_z = nullptr;      // [nchains][3]
     rtmi::PtPend *d_pinfo = nullptr; // [2][rows]
-    // the task queue of the speculative sweep (rtmi_kernels.hip::pt_sweep_queue_kernel)
-    unsigned long long *d_qslots = nullptr;
-    unsigned int *d_qctl = nullptr;  // tail | head | nfinished | abort (64-byte apart), then pendcnt[nchains]
-    unsigned int qmask = 0;
-    rtmi::PtQueueArgs *d_qargs = nullptr;  // device copy of the queue's constant words
     unsigned long long *d_qstats = nullptr;  // RTMI_PT_QSTATS: where the workgroups' time went (printed by rtmi_pt_run)
-    unsigned int q_fin_target = 0;   // chains completed over all queue launches so far
-    int task_src = 0, task_fine = 0;
-    bool use_queue = false;          // RTMI_PT_QUEUE=1: the task-queue engine instead of the proportional layout (A/B)
     int *d_walloc = nullptr;         // [2][nchains] (rtmi_pt_dev.hpp::PtDev::walloc)
     int sweep_parity = 0;
     rtmi::PtSweepArgs *d_wprop = nullptr;  // device copy of the proportional engine's constant words
@@ -389,7 +381,7 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
                 (void)hipEventRecord(e, s);
         }
     };
-    if (engine == 1 && h->use_persistent && h->spec && !h->use_queue && h->nchains <= h->cus && h->d_ptdev && h->d_partial_x) {
+    if (engine == 1 && h->use_persistent && h->spec && h->nchains <= h->cus && h->d_ptdev && h->d_partial_x) {
         // the speculative sweep, workgroups dealt to the chains in proportion to their slots: one cooperative launch
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
@@ -398,26 +390,9 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
         if (launch_pt_prop(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc, h->d_set + 2 * n,
                            h->cus, h->d_ptdev, sizeof h->d, h->d_wprop, h->nspec, h->epoch, h->sweep_parity, ks, h->stream,
                            h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride,
-                           h->d_pinfo) == RTMI_OK) {
+                           h->d_pinfo, h->nrows * h->d.part_stride) == RTMI_OK) {
             h->epoch += 4096u;  // (the passes of a sweep count from a tag of its own)
             h->sweep_parity ^= 1;
-            h->launches += 1;
-            return RTMI_OK;
-        }
-        h->use_persistent = false;
-        h->engine = 0;
-        closer.e = nullptr;
-    } else if (engine == 1 && h->use_persistent && h->spec && h->use_queue && h->d_qslots && h->d_ptdev && h->d_partial_x) {
-        // the speculative sweep over the task queue: one ordinary launch of a workgroup per CU
-        if (ev0)
-            HIP_TRY(hipEventRecord(ev0, h->stream));
-        Closer closer{ev1, h->stream};
-        const size_t n = (size_t)h->nsrc;
-        if (launch_pt_queue(h->d.V, h->d.D, h->d.NL, h->ld_model, h->max_nl, h->d_set, h->d_set + n, h->nsrc, h->d_set + 2 * n,
-                            h->cus, h->d_ptdev, sizeof h->d, h->d_qargs, h->nspec, h->q_fin_target + (unsigned int)h->nchains,
-                            h->task_src, h->stream, h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x,
-                            h->d.part_stride, h->d_pinfo) == RTMI_OK) {
-            h->q_fin_target += (unsigned int)h->nchains;
             h->launches += 1;
             return RTMI_OK;
         }
@@ -572,7 +547,13 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     // Speculative proposals (rtmi_pt_dev.hpp::pt_step_spec) need the exact sums of the fused kernel's sampler form: with them
     // a chain is bit for bit the chain of the one-at-a-time step.  RTMI_PT_SPECULATE = rows per chain (0: the one-at-a-time
     // step pt_step_group).
-    int want_spec = RTMI_PT_SPECULATE_DEFAULT;
+    // Default: speculate where a pass is bound by the LATENCY of a likelihood evaluation -- a chain's workgroups hold a
+    // couple of records per lane or fewer (BASELINE config 3: 1e4 sources over 8 workgroups; 0.92 -> 0.78 ms per sweep,
+    // profiles/r04c/pt_timings.txt) -- and not where it is bound by throughput (config 4's share, 1e5 sources per chain:
+    // every speculated model that is thrown away is work the machine had no room for, 3.07 -> 3.97 ms).  Rows per chain = what
+    // one round of the step's lane groups takes (K <= 16: four groups, three rows measured best; K <= 32: two).
+    const int gx0 = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
+    int want_spec = (c.set_n / (gx0 > 0 ? gx0 : 1) <= RTMI_PT_SPECULATE_MAX_SHARE) ? (prior->kmax <= 16 ? 3 : 2) : 0;
     if (const char *e = getenv("RTMI_PT_SPECULATE"))
         want_spec = atoi(e);
     if (want_spec > PT_SPEC_MAX)
@@ -583,18 +564,6 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     const size_t nc = (size_t)nchains, K = (size_t)h->K, ldm = (size_t)ld_model, n = (size_t)c.set_n, nr = (size_t)h->nrows;
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);     // workgroups per CHAIN (persistent engine)
     h->gx_launch = batch_grid_x(h->nrows, h->max_nl, c.set_n, c.cus);    // workgroups per ROW of the batched launch
-    // queue engine: a row is evaluated as tasks of about task_src loaded sources (RTMI_PT_TASK_SRC; 2560 = 2.5 records per
-    // lane of a 1024-thread workgroup: enough to keep the lanes refilled, little enough for one round of the record area)
-    h->task_src = 2560;   // RTMI_PT_TASK_SRC: while the rings are backed up (the record area of a task is sized for this)
-    h->task_fine = 1024;  // RTMI_PT_TASK_FINE: while workgroups are idle
-    if (const char *e = getenv("RTMI_PT_TASK_SRC"))
-        h->task_src = atoi(e) >= 64 ? atoi(e) : h->task_src;
-    if (const char *e = getenv("RTMI_PT_TASK_FINE"))
-        h->task_fine = atoi(e) >= 64 ? atoi(e) : h->task_fine;
-    if (h->task_fine > h->task_src)
-        h->task_fine = h->task_src;
-    int nw_max = (int)((c.set_n + h->task_fine - 1) / h->task_fine);
-    nw_max = nw_max < 1 ? 1 : (nw_max > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw_max);
     const int pstride = gx > h->gx_launch ? gx : h->gx_launch;  // (with the speculative step a row's sums are ONE accumulator)
     const size_t nf64 = 2 * nc * K + 2 * nr * K + 4 * nc + nr + 2 * nr * ldm;
     const size_t ni32 = nc + 3 * nr;
@@ -616,7 +585,6 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
               hipMalloc((void **)&h->d_pinfo, 2 * nr * sizeof(rtmi::PtPend)) == hipSuccess &&
               hipMalloc((void **)&h->d_cdf, (size_t)ncdf * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&h->d_walloc, 2 * nc * sizeof(int)) == hipSuccess &&
-              hipMalloc((void **)&h->d_qctl, (32 * RTMI_PTQ_RINGS + 32 + 2 * nc) * sizeof(unsigned int)) == hipSuccess &&
               (!fused_path || hipMalloc((void **)&h->d_partial_x, 4 * nr * (size_t)pstride * sizeof(unsigned long long)) == hipSuccess);
     // The residual cache of the incremental likelihood (the chains' current residuals + one row per model row, twice with the
     // speculative step: the two sets alternate) and its counters exist only where they are read: the incremental likelihood
@@ -638,22 +606,13 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     } else {
         h->incremental = false;
     }
-    if (ok && h->spec) {
-        // the ring holds every task that can be out at once (every row of every chain in nw_max shares) + one poison per workgroup
-        size_t need = 2 * (nr * (size_t)nw_max + (size_t)c.cus + 64);
-        size_t cap = 1024;
-        while (cap < need)
-            cap *= 2;
-        h->qmask = (unsigned int)(cap - 1);
-        ok = hipMalloc((void **)&h->d_qslots, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long)) == hipSuccess &&
-             hipMemsetAsync(h->d_qslots, 0, RTMI_PTQ_RINGS * cap * sizeof(unsigned long long), h->stream) == hipSuccess;
-    }
     if (ok) {
         std::vector<int> w0(2 * nc, 3);  // (k = 1)
         ok = hipMemcpy(h->d_walloc, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (const char *e = getenv("RTMI_PT_QUEUE"))
-        h->use_queue = strcmp(e, "0") != 0;
+    if (ok && h->spec && getenv("RTMI_PT_QSTATS"))  // diagnostic: where the workgroups' time goes (printed by rtmi_pt_run)
+        ok = hipMalloc((void **)&h->d_qstats, 8 * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemset(h->d_qstats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         rtmi::PtSweepArgs w;
         memset(&w, 0, sizeof w);
@@ -663,32 +622,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         w.abort_ = h->d_sync + 2 * (size_t)h->nchains;
         w.nspec = h->nspec;
         w.walloc = h->d_walloc;
+        w.stats = h->d_qstats;
         ok = hipMalloc((void **)&h->d_wprop, sizeof w) == hipSuccess && hipMemcpy(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice) == hipSuccess;
-    }
-    const size_t nqctl = 32 * RTMI_PTQ_RINGS + 32 + 2 * nc;
-    if (ok)
-        ok = hipMemsetAsync(h->d_qctl, 0, nqctl * sizeof(unsigned int), h->stream) == hipSuccess;
-    if (ok && h->spec) {
-        rtmi::PtQueueArgs q;
-        memset(&q, 0, sizeof q);
-        q.slots = h->d_qslots;
-        q.ctl = h->d_qctl;                               // per ring: tail, head (cache lines of their own)
-        q.nfinished = h->d_qctl + 32 * RTMI_PTQ_RINGS;
-        q.abort_ = h->d_qctl + 32 * RTMI_PTQ_RINGS + 16;
-        q.pendcnt = h->d_qctl + 32 * RTMI_PTQ_RINGS + 32;
-        q.rem = q.pendcnt + nc;
-        q.qmask = h->qmask;
-        q.nchains = h->nchains;
-        q.nspec = h->nspec;
-        q.task_fine = h->task_fine;
-        q.task_coarse = h->task_src;
-        if (getenv("RTMI_PT_QSTATS")) {
-            ok = hipMalloc((void **)&h->d_qstats, 8 * sizeof(unsigned long long)) == hipSuccess &&
-                 hipMemset(h->d_qstats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
-            q.stats = h->d_qstats;
-        }
-        ok = hipMalloc((void **)&h->d_qargs, sizeof q) == hipSuccess &&
-             hipMemcpy(h->d_qargs, &q, sizeof q, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok)
         ok = hipMemsetAsync(h->d_sync, 0, (2 * nc + 1) * sizeof(unsigned int), h->stream) == hipSuccess &&
@@ -787,7 +722,6 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.spec_step = h->spec ? 1 : 0;
     d.part_stride = pstride;
     d.gx_launch = h->gx_launch;
-    d.task_src = h->task_src;
     if (ok) {
         double *f = h->d_f64;
         d.z = f, f += nc * K;
@@ -876,7 +810,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
                     h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x,
-                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qslots, h->d_qctl, h->d_qargs, h->d_qstats, h->d_walloc, h->d_wprop};
+                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qstats, h->d_walloc, h->d_wprop};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -1266,8 +1200,8 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
         HIP_TRY(hipMemcpy(st, h->d_qstats, sizeof st, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(h->d_qstats, 0, sizeof st));
         if (st[5] > 0)
-            fprintf(stderr, "rtmi: queue sweeps (%d): %llu tasks (%.1f us each), %llu steps (%.1f us each); of the workgroups' time "
-                            "%.1f %% in tasks, %.1f %% in steps, %.1f %% waiting for a task\n", nsweeps, st[3],
+            fprintf(stderr, "rtmi: speculative sweeps (%d): %llu likelihood shares (%.1f us each), %llu steps (%.1f us each); of the "
+                            "workgroups' time %.1f %% in the likelihood, %.1f %% in steps, %.1f %% waiting\n", nsweeps, st[3],
                     st[3] ? 0.01 * (double)st[0] / (double)st[3] : 0.0, st[4], st[4] ? 0.01 * (double)st[1] / (double)st[4] : 0.0,
                     100.0 * (double)st[0] / (double)st[5], 100.0 * (double)st[1] / (double)st[5], 100.0 * (double)st[2] / (double)st[5]);
     }

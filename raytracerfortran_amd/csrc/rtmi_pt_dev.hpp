@@ -74,7 +74,6 @@ struct PtDev {
     rtmi::PtPend *pinfo;  // [2][nchains * nspec] what a later pass needs to know about an accepted proposal (rtmi_kernels.h)
     unsigned long long *acc;  // [rows][part_stride][4] = partial_x, writable: the step zeroes the accumulator of every row it proposes
     int gx_launch;        // per-slot engine: workgroups per row of the batched launch (rowwg of every evaluated row)
-    int task_src;         // queue engine: sources per task -- a row is evaluated as ceil(loaded sources / task_src) tasks
     int *walloc;          // [2][nchains] weights (slots of the chain's sweep, 2 k + 1) by which pt_sweep_prop_kernel deals its
                           // workgroups to the chains; an evaluation (rtmi_pt_evaluate) refreshes both halves
 };
@@ -445,8 +444,7 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // residuals to r2cur.
 // begin: first step of a sweep.  eval: decide an evaluation of the current state (rtmi_pt_evaluate) and propose nothing.
 // wg_total: > 0 workgroups the chain's rows share in the next pass (they are dealt to the evaluated rows round-robin),
-// 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows), < 0 = queue engine: a row is
-// cut into tasks of about -wg_total loaded sources.
+// 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows).
 // Called by ALL 64 lanes of a wave for one chain.
 #define PT_SPEC_MAX 4
 
@@ -864,10 +862,6 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its evaluated rows
                     nw = (wg_total - my_a[r] + nact - 1) / nact;
                     nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
-                } else if (wg_total < 0) {                   // queue engine: tasks of about -wg_total loaded sources
-                    const long long loaded = (long long)d.nsrc - (d.incremental ? n0 : 0), T = -(long long)wg_total;
-                    nw = (int)((loaded + T - 1) / T);
-                    nw = nw < 1 ? 1 : (nw > RTMI_PTQ_MAX_NW ? RTMI_PTQ_MAX_NW : nw);
                 }
                 d.rowwg[m0 + my_e[r]] = nw;
                 d.inc[m0 + my_e[r]].n0 = n0;

@@ -25,15 +25,15 @@ LIMITS = {
     "_ZN4rtmi12fused_kernelIdLb0ELb0ELb1ELb0ELi1ELb0EEE": (0, 124, 112, 0),
     # the sampler's likelihood kernel (exact sums, residual cache, sorted sources): a handful around the loop, none in it [8, 128, 112, 9]
     "_ZN4rtmi12fused_kernelIdLb0ELb0ELb1ELb0ELi1ELb1EEE": (16, 128, 125, 14),
-    # the speculative sweep over the task queue, k <= 21 (the step and the queue are real calls: what is left are the
-    # values that live across them)                                                           [118, 128, 177, 70]
-    "_ZN4rtmi21pt_sweep_queue_kernelILi1EEE": (140, 128, 200, 85),
-    # ... and for deeper models (table form 0)                                                [185, 128, 177, 112]
-    "_ZN4rtmi21pt_sweep_queue_kernelILi0EEE": (215, 128, 200, 130),
+    # the speculative sweep (workgroups dealt to the chains in proportion to their slots), k <= 21: the layout, the step and
+    # the handshakes are real calls and the loop state sits in LDS; what is left are the body's own        [120, 128, 193, 70]
+    "_ZN4rtmi20pt_sweep_prop_kernelILi1EEE": (140, 128, 215, 85),
+    # ... and for deeper models (table form 0)                                                [192, 128, 183, 115]
+    "_ZN4rtmi20pt_sweep_prop_kernelILi0EEE": (220, 128, 210, 132),
     # the one-at-a-time persistent sweep (RTMI_PT_SPECULATE=0), k <= 21                       [30, 128, 213, 25]
     "_ZN4rtmi15pt_sweep_kernelILi1ELb1EEE": (40, 128, 235, 32),
-    # ... and for deeper models: regressed with the sorted-source form of the body (134 scratch instructions against 60 in
-    # round 3) and still 17 % faster than round 3's on config 4's share (profiles/r04a/pt_timings.txt); not the default engine
+    # ... and for deeper models: more scratch than round 3's (60 instructions) with the sorted-source form of the body, and still
+    # 17 % faster than round 3's on config 4's share (profiles/r04c/pt_timings.txt), where it is the default engine
     "_ZN4rtmi15pt_sweep_kernelILi0ELb1EEE": (150, 128, 210, 100),
 }
 
