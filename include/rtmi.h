@@ -184,6 +184,10 @@ int rtmi_pt_speculation(rtmi_pt *h, int64_t *out4);
 int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int *level, const double *beta_of_level,
                        int nlevels);
 int rtmi_pt_get_ladder(rtmi_pt *h, int *level, int64_t *swap_stats2 /* accepted, proposed */);
+/* New inverse temperatures for the ladder's levels, in place: the assignment of chains to levels, the exchange's counters
+ * and its position in the random stream are kept.  For the burn-in adaptation of prjmh_temper_rf.f90:363-383 (dTlog x 1.02 /
+ * x 0.98 on the rolling exchange acceptance), which raymod / tempering.py offer as an option. */
+int rtmi_pt_set_ladder_betas(rtmi_pt *h, const double *beta_of_level, int nlevels);
 int rtmi_pt_swap_round(rtmi_pt *h, rtmi_comm *comm);
 int rtmi_pt_swap_round_host(rtmi_pt *h, const double *logl_all);
 int rtmi_pt_swap_decide(int nchains_total, const double *logl_all, int *level, const double *beta_of_level, int nlevels,

@@ -8,7 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracerfortran_amd as rt
-rt.load_library(); rt.init(0)
+rt.load_library(os.environ.get('RTMI_AB_LIB') or None); rt.init(0)   # RTMI_AB_LIB: another build (profiles/ab_prev/...)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 rng = np.random.default_rng(2025)
 d = np.cumsum(rng.uniform(200, 600, 20)); v = np.sort(rng.uniform(1500, 6500, 21))

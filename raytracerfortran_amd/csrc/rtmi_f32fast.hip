@@ -19,9 +19,11 @@
 // stopping tolerance (tests/test_gpu_f32fast.py).
 //
 // Machine mapping: persistent workgroups of 256 lanes; per tile of 1024 sources a counting sort by source layer in LDS (so
-// that the 64 lanes of a wave walk the same number of layers), one source per lane, the per-stack coefficient rows
-// {c, H r, H / V} as 16-byte LDS entries (one ds_read_b128 per layer, broadcast when the wave shares a row), v_rsq_f32 for
-// every 1 / sqrt, results returned to input order through LDS so that the stores are coalesced.  12 B of HBM per source.
+// that the 64 lanes of a wave walk the same number of layers), one source per lane, the per-stack coefficient rows stored
+// as PAIRS of layers -- {c_i, c_i+1, (H r)_i, (H r)_i+1} and {(H / V)_i, (H / V)_i+1} -- so that one ds_read_b128 (broadcast when
+// the wave shares a row) feeds two layer terms and the arithmetic on them is packed (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32: two layers per instruction; the kernel is bound by vector issue), v_rsq_f32 for every 1 / sqrt, results
+// returned to input order through LDS so that the stores are coalesced.  12 B of HBM per source.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -37,14 +39,35 @@ namespace rtmi {
 #endif
 #define F32F_TILE (F32F_BLOCK * F32F_PER_THREAD)
 #define F32F_MAXIT 12
+#ifndef F32F_CONV_REL
+#define F32F_CONV_REL 1e-4f  // the last step's relative size below which the iterate it lands on is the root to roundoff (see the loop)
+#endif
+
+#ifdef F32F_CLOCKS
+// instrumented build (profiles/ubench/f32fast_phases.hip): cycles of wave 0 of every workgroup per phase, kept in registers
+// and written once when the workgroup leaves
+__device__ unsigned long long f32f_clk[8 * 1024];
+#define F32F_STAMP(i)                                  \
+    do {                                               \
+        const unsigned long long now_ = clock64();     \
+        clk_acc_[i] += now_ - clk_prev_;               \
+        clk_prev_ = now_;                              \
+    } while (0)
+#else
+#define F32F_STAMP(i)
+#endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // a register pair: the operand of the packed single-precision instructions
 
 __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int NL = a.nlayers, W = NL + 1;  // source layers il = 0 .. NL
     const int WS = (W + 3) & ~3;           // row stride: the layer loops run four entries at a time over zero-padded rows
-    float4 *tab = reinterpret_cast<float4 *>(lds_raw);           // [W][WS] tab[il * WS + i] = {c_i, H_i r_i, H_i / V_i, 0}, i < il; zeros from i = il on
-    float4 *diag = tab + (size_t)W * WS;                         // [W] the source's own layer: {c_l, r_l, 1 / V_l, sum_{i < il} H_i r_i}
+    const int WH = WS >> 1;                // pairs of layers per row (even)
+    float4 *tabA = reinterpret_cast<float4 *>(lds_raw);          // [W][WH] tabA[il * WH + i / 2] = {c_i, c_i+1, H_i r_i, H_i+1 r_i+1}, zeros from layer il on
+    float2 *tabB = reinterpret_cast<float2 *>(tabA + (size_t)W * WH);  // [W][WH] {H_i / V_i, H_i+1 / V_i+1}, likewise
+    float4 *diag = reinterpret_cast<float4 *>(tabB + (size_t)W * WH);  // [W] the source's own layer: {c_l, r_l, 1 / V_l, sum_{i < il} H_i r_i}
     float4 *diag2 = diag + W;                                    // [W] {sum of H r over the stack's fastest full layers, sum of H r / sqrt(c)
                                                                  //      over its slower ones, 1 / sqrt(c_l) (0 if the own layer is a fastest one), 0}
     float *vmi = reinterpret_cast<float *>(diag2 + W);           // [W] 1 / vmax of the stack
@@ -55,8 +78,16 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     float *pout = tout + F32F_TILE;                              // [TILE] ray parameters in input order
     uint32_t *hist = reinterpret_cast<uint32_t *>(pout + F32F_TILE);  // [W] counts, then first positions
     uint32_t *sidx = hist + ((W + 3) & ~3);                           // [TILE] local index | layer << 16 of the sorted record
-    double *vmaxd = reinterpret_cast<double *>(sidx + F32F_TILE);      // [W] running maximum of the velocities (staging)
+    double *vmaxd = reinterpret_cast<double *>(sidx + F32F_TILE);      // [W] running maximum of the velocities (staging, like the next four)
+    double *ivm = vmaxd + W;                                           // [W] 1 / vmax of the stack
+    double *ivm2 = ivm + W;                                            // [W] 1 / vmax^2
+    double *ivl = ivm2 + W;                                            // [W] 1 / V of the layer
+    double *hvd = ivl + W;                                             // [W] H / V of the layer
 
+#ifdef F32F_CLOCKS
+    unsigned long long clk_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long clk_prev_ = clock64();
+#endif
     // ---- the model's tables (once per workgroup; the model itself goes through LDS: one round trip to memory) ---------------
     float *Vs = tout;  // [W] velocities, staged in the results area (free until the first tile)
     for (int i = threadIdx.x; i < W; i += F32F_BLOCK)
@@ -84,49 +115,85 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
         }
         return;
     }
+    // per layer and per stack height, one lane each: the divisions of the whole staging (the pairs below only multiply)
+    auto thick = [&](int i) { return i == 0 ? (double)D[0] : (double)D[i] - (double)D[i - 1]; };
     for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
         double m = (double)Vs[0];
         for (int i = 1; i <= il; ++i)
             m = fmax(m, (double)Vs[i]);
+        const double im = 1.0 / m, vl = (double)Vs[il];
         vmaxd[il] = m;
-        vmi[il] = (float)(1.0 / m);
+        ivm[il] = im;
+        ivm2[il] = 1.0 / (m * m);
+        ivl[il] = 1.0 / vl;
+        hvd[il] = il < NL ? thick(il) / vl : 0.0;
+        vmi[il] = (float)im;
     }
     __syncthreads();
-    auto thick = [&](int i) { return i == 0 ? (double)D[0] : (double)D[i] - (double)D[i - 1]; };
-    for (int e = threadIdx.x; e < W * WS; e += F32F_BLOCK) {
-        const int il = e / WS, i = e - il * WS;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (i < il) {
-            const double vm = vmaxd[il], vi = (double)Vs[i], h = thick(i);
-            v.x = (float)((vm - vi) * (vm + vi) / (vm * vm));
-            v.y = (float)(h * (vi / vm));
-            v.z = (float)(h / vi);
+    F32F_STAMP(6);
+    // One row (stack) per group of 32 lanes, a layer of it per lane: the table entries and the three sums over the stack that
+    // the start values need, the sums by a fixed tree over the group (the same bits on every launch).  [Round 3 had one
+    // LANE per row walk its layers with three double-precision divides and a square root per layer, and every workgroup --
+    // four per CU, on the same vector units -- does this before its first source: 10 us of a 44 us launch at config 5's
+    // per-GPU share (profiles/r04m/f32fast_phases.txt).  Here a pair (stack, layer) costs a dozen multiplications: the
+    // reciprocals are per stack / per layer (above), and the saturated offset's 1 / sqrt(c) is needed to 1e-6 only (the
+    // start value it bounds carries that margin), so the single-precision v_rsq_f32 serves.]
+    {
+        float *fa = reinterpret_cast<float *>(tabA);
+        float *fb = reinterpret_cast<float *>(tabB);
+        const int g = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        for (int il = g; il < W; il += F32F_BLOCK / 32) {
+            const double vm = vmaxd[il], im = ivm[il], im2 = ivm2[il];
+            double afull = 0.0, hc = 0.0, binf = 0.0;
+            for (int i = l32; i < WS; i += 32) {
+                float c = 0.0f, hr = 0.0f, hv = 0.0f;
+                if (i < il) {
+                    const double vi = (double)Vs[i], ai = thick(i) * (vi * im);
+                    c = (float)(((vm - vi) * (vm + vi)) * im2);
+                    hr = (float)ai;
+                    hv = (float)hvd[i];
+                    afull += ai;
+                    if (c > 0.0f)
+                        binf += ai * (double)__builtin_amdgcn_rsqf(c);
+                    else
+                        hc += ai;
+                }
+                const int pr = il * WH + (i >> 1), hf = i & 1;
+                fa[4 * pr + hf] = c;
+                fa[4 * pr + 2 + hf] = hr;
+                fb[2 * pr + hf] = hv;
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {  // stays inside the group of 32
+                afull += __shfl_xor(afull, off, 64);
+                hc += __shfl_xor(hc, off, 64);
+                binf += __shfl_xor(binf, off, 64);
+            }
+            if (l32 == 0) {
+                const double vl = (double)Vs[il];
+                const float cl = (float)(((vm - vl) * (vm + vl)) * im2);
+                diag[il] = make_float4(cl, (float)(vl * im), (float)ivl[il], (float)afull);
+                // rounded so that the start value stays a LOWER bound of the root: hc up, the saturated offset up (the margin
+                // covers v_rsq_f32's 1e-7)
+                diag2[il] = make_float4((float)(hc * (1.0 + 1e-6)), (float)(binf * (1.0 + 2e-6)), cl > 0.0f ? (float)(1.0 / sqrt((double)cl)) : 0.0f, 0.0f);
+            }
         }
-        tab[e] = v;
-    }
-    for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
-        const double vm = vmaxd[il], vl = (double)Vs[il];
-        double afull = 0.0, hc = 0.0, binf = 0.0;
-        for (int i = 0; i < il; ++i) {
-            const double vi = (double)Vs[i], ai = thick(i) * (vi / vm);
-            const float ci = (float)((vm - vi) * (vm + vi) / (vm * vm));  // as tabulated
-            afull += ai;
-            if (ci > 0.0f)
-                binf += ai / sqrt((double)ci);
-            else
-                hc += ai;
-        }
-        const float cl = (float)((vm - vl) * (vm + vl) / (vm * vm));
-        diag[il] = make_float4(cl, (float)(vl / vm), (float)(1.0 / vl), (float)afull);
-        // rounded so that the start value stays a LOWER bound of the root: hc up, the saturated offset up
-        diag2[il] = make_float4((float)(hc * (1.0 + 1e-6)), (float)(binf * (1.0 + 1e-6)), cl > 0.0f ? (float)(1.0 / sqrt((double)cl)) : 0.0f, 0.0f);
     }
     __syncthreads();
 
+    F32F_STAMP(0);  // the model's tables
     const int lane = threadIdx.x & 63;
-    const int64_t ntiles = (a.nsrc + F32F_TILE - 1) / F32F_TILE;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base = tile * F32F_TILE;
+    // Every workgroup a CONTIGUOUS slice of the sources, cut into equal tiles of at most F32F_TILE.  [Round 3 dealt fixed tiles
+    // of 1024 round-robin: at config 5's per-GPU share -- 1.25e6 sources = 1221 tiles for 1024 workgroups -- a fifth of the
+    // workgroups took two tiles and the rest one.  Equal slices measured the same (profiles/r04j/f32fast.txt: the four
+    // workgroups of a CU even that out between them); kept because a slice is also one contiguous read.]
+    const int64_t per = ((a.nsrc + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    const int64_t s0 = (int64_t)blockIdx.x * per, s1 = s0 + per < a.nsrc ? s0 + per : a.nsrc;
+    const int nsub = s1 > s0 ? (int)((s1 - s0 + F32F_TILE - 1) / F32F_TILE) : 0;
+    const int64_t sub = nsub ? ((s1 - s0 + nsub - 1) / nsub + 63) / 64 * 64 : 0;  // <= F32F_TILE
+    for (int t = 0; t < nsub; ++t) {
+        const int64_t base = s0 + t * sub;
+        const int64_t lim = base + sub < s1 ? base + sub : s1;  // this tile's sources: [base, lim)
         // ---- load, locate, count ----------------------------------------------------------------------------------
         for (int i = threadIdx.x; i < W; i += F32F_BLOCK)
             hist[i] = 0;
@@ -137,10 +204,14 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 #pragma unroll
         for (int j = 0; j < F32F_PER_THREAD; ++j) {
             const int64_t k = base + j * F32F_BLOCK + threadIdx.x;
-            const bool valid = k < a.nsrc;
+            const bool valid = k < lim;
             z[j] = valid ? a.d_src_depth[k] : 0.0f;
             R[j] = valid ? a.d_src_offset[k] : 0.0f;
         }
+#ifdef F32F_CLOCKS
+        if (!(z[0] + R[0] == 12345.678f))  // (waits for the first loads)
+#endif
+            F32F_STAMP(1);  // sources loaded
         // whichLayer (:9-32): 1-based index of the first interface strictly below z; NL + 1 below the last one; NL when z sits
         // exactly on the last interface (neither > nor <).  With sorted interfaces (this mode's precondition, checked above)
         // that index is 1 + the number of interfaces <= z.  il = index - 1: the source's layer.
@@ -164,7 +235,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 nl = NL;  // NaN depth: every comparison of the reference is false
             il[j] = nl - 1;
             const int64_t k = base + j * F32F_BLOCK + threadIdx.x;
-            rank[j] = k < a.nsrc ? atomicAdd(&hist[il[j]], 1u) : 0u;
+            rank[j] = k < lim ? atomicAdd(&hist[il[j]], 1u) : 0u;
         }
         __syncthreads();
         if (threadIdx.x < 64) {
@@ -184,7 +255,7 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 #pragma unroll
         for (int j = 0; j < F32F_PER_THREAD; ++j) {
             const int loc = j * F32F_BLOCK + threadIdx.x;
-            if (base + loc < a.nsrc) {
+            if (base + loc < lim) {
                 const uint32_t pos = hist[il[j]] + rank[j];
                 sz[pos] = z[j];
                 sR[pos] = R[j];
@@ -192,7 +263,8 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
             }
         }
         __syncthreads();
-        const int nvalid = (int)((a.nsrc - base) < F32F_TILE ? (a.nsrc - base) : F32F_TILE);
+        F32F_STAMP(2);  // located, counted, sorted
+        const int nvalid = (int)(lim - base);
         // ---- solve, one sorted record per lane ------------------------------------------------------------------------
         for (int q0 = (threadIdx.x & ~63); q0 < nvalid; q0 += F32F_BLOCK) {
             const int q = q0 + lane;
@@ -216,7 +288,8 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 const float4 dg = diag[ile];
                 const float hl = zq - D[ile - 1];
                 const float cl = dg.x, al = hl * dg.y, bl = hl * dg.z;
-                const float4 *row = tab + (size_t)ile * WS;
+                const float4 *rowA = tabA + (size_t)ile * WH;
+                const float2 *rowB = tabB + (size_t)ile * WH;
                 // two lower bounds of the root: X(s) <= s sum H_i r_i, and X(s) <= hc s + B with hc the fastest layers' share
                 // and B what the slower layers can cover at most (s -> infinity): the second one starts a near-critical ray,
                 // the kind that would otherwise climb for ten iterations, next to its root
@@ -247,17 +320,22 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 bool conv = !valid || ilq == 0;
                 for (int it = 0; it < F32F_MAXIT && __any(!conv); ++it) {
                     const float ss = s * s;
-                    float S1 = 0.0f, S3 = 0.0f;
+                    // two layers per instruction: the sums as {even layers, odd layers}, added at the end
+                    const v2f ss2 = {ss, ss}, one2 = {1.0f, 1.0f};
+                    v2f S1v = {0.0f, 0.0f}, S3v = {0.0f, 0.0f};
                     for (int i = 0; i < ilw; i += 4) {  // ilw is a scalar: no lane is masked, rows are zero past the lane's own stack
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float2 e = *reinterpret_cast<const float2 *>(row + i + u);  // {c, H r}
-                            const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
-                            const float ty = e.y * y;
-                            S1 += ty;
-                            S3 = __builtin_fmaf(ty * y, y, S3);
+                        for (int u = 0; u < 2; ++u) {
+                            const float4 e = rowA[(i >> 1) + u];  // {c_i, c_i+1, (H r)_i, (H r)_i+1}
+                            const v2f c = {e.x, e.y}, hr = {e.z, e.w};
+                            const v2f w = __builtin_elementwise_fma(c, ss2, one2);
+                            const v2f y = {__builtin_amdgcn_rsqf(w.x), __builtin_amdgcn_rsqf(w.y)};
+                            const v2f ty = hr * y;
+                            S1v += ty;
+                            S3v = __builtin_elementwise_fma(ty * y, y, S3v);
                         }
                     }
+                    float S1 = S1v.x + S1v.y, S3 = S3v.x + S3v.y;
                     {
                         const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(cl, ss, 1.0f));
                         const float ty = al * y;
@@ -266,23 +344,33 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                     }
                     const float ds = (Rq - s * S1) * __builtin_amdgcn_rcpf(S3);
                     const float sn = s + ds;
-                    // the iterates climb (X is concave: a Newton step from the left stays left of the root), so a step that
-                    // is not a climb of more than 1e-6 s any more is the roundoff floor; also true for NaN: such a lane stops
-                    const bool now = !(ds > 1e-6f * sn) && !(ds < -1e-4f * s);  // (a step back that is no roundoff: go on)
+                    // The iterates climb (X is concave: a Newton step from the left stays left of the root).  With e = root - s the
+                    // step is ds = e (1 + O(e / s)) and the next error is e' = |X''(xi)| e^2 / (2 X'(s)), xi in [s, root];
+                    // X' = sum a_i y_i^3 decreases and  s |X''| / X' = 3 sum a_i y_i^3 (c_i s^2 y_i^2) / sum a_i y_i^3 < 3,  so
+                    // e' / root < 1.5 (e / root)^2: a step of less than 1e-4 s lands within 2e-8 of the root, a quarter of the
+                    // single-precision spacing -- the evaluation that would only confirm it is not made [round 3 went on until
+                    // the step itself was below 1e-6 s: one more pass over the stack for most waves].  Also true for NaN: such a
+                    // lane stops.
+                    const bool now = !(ds > F32F_CONV_REL * sn) && !(ds < -1e-4f * s);  // (a step back that is no roundoff: go on)
                     s = conv ? s : sn;  // a converged lane is frozen: its result does not depend on its neighbours
                     conv = conv || now;
                 }
                 const float ss = s * s;
-                float S1 = 0.0f, SB = 0.0f;
+                const v2f ss2 = {ss, ss}, one2 = {1.0f, 1.0f};
+                v2f S1v = {0.0f, 0.0f}, SBv = {0.0f, 0.0f};
                 for (int i = 0; i < ilw; i += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 e = row[i + u];
-                        const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(e.x, ss, 1.0f));
-                        S1 = __builtin_fmaf(e.y, y, S1);
-                        SB = __builtin_fmaf(e.z, y, SB);
+                    for (int u = 0; u < 2; ++u) {
+                        const float4 e = rowA[(i >> 1) + u];
+                        const float2 b = rowB[(i >> 1) + u];
+                        const v2f c = {e.x, e.y}, hr = {e.z, e.w}, hv = {b.x, b.y};
+                        const v2f w = __builtin_elementwise_fma(c, ss2, one2);
+                        const v2f y = {__builtin_amdgcn_rsqf(w.x), __builtin_amdgcn_rsqf(w.y)};
+                        S1v = __builtin_elementwise_fma(hr, y, S1v);
+                        SBv = __builtin_elementwise_fma(hv, y, SBv);
                     }
                 }
+                float S1 = S1v.x + S1v.y, SB = SBv.x + SBv.y;
                 {
                     const float y = __builtin_amdgcn_rsqf(__builtin_fmaf(cl, ss, 1.0f));
                     S1 = __builtin_fmaf(al, y, S1);
@@ -307,20 +395,28 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
                 pout[loc] = Rs < 0.0f ? -pp : pp;
             }
         }
+        F32F_STAMP(3);  // wave 0's own solves
         __syncthreads();
+        F32F_STAMP(4);  // ... waiting for the other waves
         // ---- results back in input order: coalesced stores ----------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < F32F_PER_THREAD; ++j) {
             const int loc = j * F32F_BLOCK + threadIdx.x;
             const int64_t k = base + loc;
-            if (k < a.nsrc) {
+            if (k < lim) {
                 a.d_timeP[k] = tout[loc];
                 if (a.d_p_final)
                     a.d_p_final[k] = pout[loc];
             }
         }
         __syncthreads();  // before the next tile reuses the staging arrays
+        F32F_STAMP(5);  // stores issued
     }
+#ifdef F32F_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; ++i)
+            f32f_clk[blockIdx.x * 8 + i] += clk_acc_[i];
+#endif
 }
 
 }  // namespace rtmi
@@ -329,12 +425,12 @@ extern "C" size_t rtmi_f32fast_lds_bytes(int nlayers)
 {
     const size_t W = (size_t)nlayers + 1;
     const size_t WS = (W + 3) & ~(size_t)3;
-    size_t b = W * WS * sizeof(float4) + 2 * W * sizeof(float4) + ((W + 3) & ~(size_t)3) * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
+    size_t b = W * (WS / 2) * (sizeof(float4) + sizeof(float2)) + 2 * W * sizeof(float4) + ((W + 3) & ~(size_t)3) * sizeof(float) + (((size_t)nlayers + 3) & ~(size_t)3) * sizeof(float);
     b += (size_t)4 * F32F_TILE * sizeof(float);                 // sz, sR, tout, pout
     b += ((W + 3) & ~(size_t)3) * sizeof(uint32_t);             // hist
     b += (size_t)F32F_TILE * sizeof(uint32_t);                  // sidx
     b = (b + 7) & ~(size_t)7;
-    b += W * sizeof(double);                                    // vmaxd
+    b += 5 * W * sizeof(double);                                // vmaxd, ivm, ivm2, ivl, hvd
     return b + 16;
 }
 

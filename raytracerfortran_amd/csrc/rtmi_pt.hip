@@ -984,6 +984,28 @@ int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int
     return RTMI_OK;
 }
 
+// New inverse temperatures for the levels of the ladder in place: who sits on which level, the exchange's counters and its
+// position in the random stream stay as they are (the burn-in adaptation of prjmh_temper_rf.f90:363-383 re-spaces the ladder
+// while the run goes on).
+int rtmi_pt_set_ladder_betas(rtmi_pt *h, const double *beta_of_level, int nlevels)
+{
+    if (!h || !beta_of_level)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_ladder_betas: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->d_level || nlevels != h->nlevels)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_set_ladder_betas: %s", h->d_level ? "nlevels differs from the ladder's" : "no ladder (call rtmi_pt_set_ladder first)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<int> lev((size_t)h->nct);
+    HIP_TRY(hipMemcpy(lev.data(), h->d_level, lev.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<double> b((size_t)h->nchains);
+    for (int c = 0; c < h->nchains; ++c)
+        b[(size_t)c] = beta_of_level[lev[(size_t)(h->first + c)]];
+    HIP_TRY(hipMemcpy(h->d_beta_of_level, beta_of_level, (size_t)nlevels * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d.beta, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    return RTMI_OK;
+}
+
 int rtmi_pt_get_ladder(rtmi_pt *h, int *level, int64_t *swap_stats2)
 {
     if (!h || !h->d_level)

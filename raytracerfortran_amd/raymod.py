@@ -57,6 +57,7 @@ SIGNATURES = {
     "rtmi_pt_stream_positions": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "rtmi_pt_speculation": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_set_ladder": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]),
+    "rtmi_pt_set_ladder_betas": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "rtmi_pt_get_ladder": (ctypes.c_int, [_vp, _ip, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_swap_round": (ctypes.c_int, [_vp, _vp]),
     "rtmi_pt_swap_round_host": (ctypes.c_int, [_vp, _dp]),
@@ -385,6 +386,11 @@ class NativeChains:
         _check(self.lib.rtmi_pt_set_ladder(self.h, int(nchains_total), int(first_chain), lev.ctypes.data_as(_ip),
                                            b.ctypes.data_as(_dp), b.size))
         self.nct = int(nchains_total)
+
+    def set_ladder_betas(self, beta_of_level):
+        """New inverse temperatures for the ladder's levels in place (levels, exchange counters and random stream kept)."""
+        b = _as_f64(beta_of_level)
+        _check(self.lib.rtmi_pt_set_ladder_betas(self.h, b.ctypes.data_as(_dp), b.size))
 
     def get_ladder(self):
         lev = np.empty(self.nct, np.int32)

@@ -121,10 +121,11 @@ def read_sample_file(path: str, nlmx: int) -> List[dict]:
 
 
 def run_from_files(directory: str, nsweeps: int, nchains: int = 8, seed: int = 1, burnin: int = 0, out_dir: str = None,
-                   evaluator=None):
+                   evaluator=None, adapt_ladder: bool = False):
     """Start the tempering driver the way `mpirun prjmh_temper_rf` is started in the reference's test_1 directory:
     filebase.txt -> <base>_parameter.dat, <base>_map.dat, data files; T = 1 samples go to <base>_voro_sample.txt.
-    IMAP = 1: evaluate the start model only and write <base>_mappredRT.dat / <base>_obsRT.dat (:246-268)."""
+    IMAP = 1: evaluate the start model only and write <base>_mappredRT.dat / <base>_obsRT.dat (:246-268).
+    adapt_ladder: the burn-in re-spacing of the ladder (:363-383) with the chains actually following it (tempering.Sampler)."""
     from . import tempering as T
     from . import raymod
     base_name = read_filebase(directory)
@@ -151,7 +152,7 @@ def run_from_files(directory: str, nsweeps: int, nchains: int = 8, seed: int = 1
     ev = evaluator or T.GpuEvaluator(off, dep, obs, ld=max(32, par["NLMX"] + 2))
     engine = T.Sampler if evaluator is not None else T.NativeSampler
     s = engine(prior, ev, ndata=obs.size, nchains_total=nchains, nptchains1=par["NPTCHAINS1"], dTlog=par["dTlog"],
-               seed=seed)
+               seed=seed, adapt_ladder=adapt_ladder)
     s.init_from_model(nodes, sd)
     import time
     t0 = time.perf_counter()

@@ -162,6 +162,8 @@ class Sampler:
     world: int = 1
     dist: object = None                # torch.distributed (initialised) or None
     dist_device: str = "cpu"           # device of the all-gather tensors ("cuda:<n>" -> RCCL)
+    adapt_ladder: bool = False         # burn-in re-spacing of the ladder (prjmh_temper_rf.f90:363-383); see adapt_after_window
+    acceptance_window: int = 150       # exchange proposals per acceptance estimate (rjmcmc_com.f90:159)
     chains: List[Chain] = field(default_factory=list)
 
     def __post_init__(self):
@@ -177,6 +179,38 @@ class Sampler:
         self.stats = {"acc_bd": 0, "prop_bd": 0, "acc_mh": 0, "prop_mh": 0, "acc_sd": 0, "prop_sd": 0,
                       "acc_swap": 0, "prop_swap": 0}
         self.swap_parity = 0
+        self.acceptance_rate = 0.25                        # prjmh_temper_rf.f90:317
+        self._win_acc = self._win_prop = 0                 # ncswap / ncswapprop of the running window (:320-321)
+        self.ladder_history = []                           # (sweep, acceptance rate, dTlog) at every window end in burn-in
+
+    # ----- burn-in ladder adaptation (opt-in) --------------------------------------------------------
+    def _window(self, acc: int, prop: int) -> bool:
+        """TEMPSWP_MH's rolling estimate (prjmh_temper_rf.f90:1371-1380): once MORE than acceptance_window exchanges were
+        proposed, the rate of that window becomes the estimate and the window restarts.  True when that happened."""
+        self._win_acc += acc
+        self._win_prop += prop
+        if self._win_prop > self.acceptance_window:
+            self.acceptance_rate = self._win_acc / self._win_prop
+            self._win_acc = self._win_prop = 0
+            return True
+        return False
+
+    def adapt_after_window(self, sweep: int) -> bool:
+        """The master's burn-in rule (prjmh_temper_rf.f90:363-383), applied when a window has just closed: an estimate
+        below 0.2 multiplies dTlog by 1.02, one above 0.5 by 0.98 -- the reference's own directions and thresholds
+        (its comment says 0.2-0.3) -- and beta of level l becomes dTlog**-l.  In the reference the workers keep the
+        betas they were started with (only the master's table changes), so the rule is nearly inert there; here the
+        chains DO get the new ladder, which is why this is an option and not the default.  Returns whether dTlog moved."""
+        old = self.dTlog
+        if self.acceptance_rate < 0.2:
+            self.dTlog *= 1.02
+        if self.acceptance_rate > 0.5:
+            self.dTlog *= 0.98
+        self.ladder_history.append((sweep, self.acceptance_rate, self.dTlog))
+        if self.dTlog == old:
+            return False
+        self.beta_of_level = np.array([self.dTlog ** (-lv) for lv in range(len(self.beta_of_level))])
+        return True
 
     # ----- initialisation -----------------------------------------------------------------------
     def init_from_prior(self):
@@ -317,7 +351,10 @@ class Sampler:
         for it in range(nsweeps):
             self.sweep()
             if (it + 1) % swap_every == 0 and self.nchains_total > 1:
+                a0, p0 = self.stats["acc_swap"], self.stats["prop_swap"]
                 self.swap_round()
+                if self._window(self.stats["acc_swap"] - a0, self.stats["prop_swap"] - p0) and self.adapt_ladder and it < burnin:
+                    self.adapt_after_window(it)
             if it >= burnin and (it - burnin + 1) % thin == 0:  # after every thin-th sweep (prjmh_temper_rf.f90:329-389)
                 for i, c in enumerate(self.chains):
                     if self.level[self.first + i] == 0:
@@ -400,14 +437,34 @@ class NativeSampler(Sampler):
         swap_every = swap_every if self.nchains_total > 1 else 0
         nrec = max(0, nsweeps - burnin)
         self.native.sample_buffer(max(1, (nrec // max(1, thin) + 1) * self.nloc))
-        if device_loop:
+        if device_loop and self.adapt_ladder and swap_every:
+            # burn-in in pieces of one acceptance window each: the counters come back, the rule is applied, the new betas go
+            # down (rtmi_pt_set_ladder_betas: levels, counters and the exchange's random stream stay as they are)
+            per_round = max(1, (self.nchains_total - 1) // 2)
+            piece = swap_every * (self.acceptance_window // per_round + 1)
+            done, nb = 0, min(burnin, nsweeps)
+            _, a0, p0 = self.native.get_ladder()
+            while done < nb:
+                n = min(piece, nb - done)
+                self.native.run(n, swap_every, self.comm, 0)
+                done += n
+                _, a1, p1 = self.native.get_ladder()
+                if self._window(a1 - a0, p1 - p0) and done < nb and self.adapt_after_window(done):
+                    self.native.set_ladder_betas(self.beta_of_level)
+                a0, p0 = a1, p1
+            self.native.run(nrec, swap_every, self.comm, thin)
+        elif device_loop:
             self.native.run(min(burnin, nsweeps), swap_every, self.comm, 0)
             self.native.run(nrec, swap_every, self.comm, thin)
         else:
             for it in range(nsweeps):
                 self.native.run(1, 0, None, 1 if (it >= burnin and (it - burnin + 1) % thin == 0) else 0)
                 if swap_every and (it + 1) % swap_every == 0:
+                    _, a0, p0 = self.native.get_ladder()
                     self.swap_round()
+                    _, a1, p1 = self.native.get_ladder()
+                    if self._window(a1 - a0, p1 - p0) and self.adapt_ladder and it < burnin and self.adapt_after_window(it):
+                        self.native.set_ladder_betas(self.beta_of_level)
         s = self.native.samples()
         out = []
         for i in np.lexsort((s["chain"], s["sweep"])):  # the ring is filled through an atomic counter: order by (sweep, chain)

@@ -150,6 +150,14 @@ module rtmi_sampler
          integer(c_int), intent(in) :: level(*)
          real(c_double), intent(in) :: beta_of_level(*)
       end function rtmi_pt_set_ladder
+      ! new betas for the ladder's levels in place (the burn-in re-spacing of prjmh_temper_rf.f90:363-383: after the master
+      ! has multiplied dTlog, beta_of_level(l) = 1/dTlog**(l-1)); levels, exchange counters and random stream are kept
+      integer(c_int) function rtmi_pt_set_ladder_betas(h, beta_of_level, nlevels) bind(C, name="rtmi_pt_set_ladder_betas")
+         import :: c_ptr, c_int, c_double
+         type(c_ptr), value :: h
+         real(c_double), intent(in) :: beta_of_level(*)
+         integer(c_int), value :: nlevels
+      end function rtmi_pt_set_ladder_betas
       integer(c_int) function rtmi_pt_run(h, nsweeps, swap_every, comm, record_every) bind(C, name="rtmi_pt_run")
          import :: c_ptr, c_int
          type(c_ptr), value :: h, comm                     ! comm = c_null_ptr when every chain is local

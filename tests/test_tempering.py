@@ -68,6 +68,45 @@ def test_tempering_helps_and_levels_stay_a_permutation():
     assert abs(vmean - 4000.0) < 300.0
 
 
+def test_burnin_ladder_adaptation_follows_the_reference_rule():
+    """prjmh_temper_rf.f90:363-383 with TEMPSWP_MH's rolling window (:1371-1380, acceptance_window = 150, rjmcmc_com.f90:159):
+    the estimate starts at 0.25 (:317), a window closes once MORE than acceptance_window exchanges were proposed, a rate
+    below 0.2 multiplies dTlog by 1.02, one above 0.5 by 0.98, and beta of level l becomes dTlog**-l."""
+    s = T.Sampler(T.Prior(), FlatEvaluator(), ndata=20, nchains_total=4, nptchains1=1, dTlog=1.5, seed=1)
+    assert s.acceptance_rate == 0.25 and not s.adapt_ladder
+    assert not s._window(10, 150)             # 150 proposals: not yet more than the window
+    assert s._window(0, 1) and abs(s.acceptance_rate - 10 / 151) < 1e-15 and s._win_prop == 0
+    assert s.adapt_after_window(7) and abs(s.dTlog - 1.5 * 1.02) < 1e-15
+    assert np.allclose(s.beta_of_level, [(1.5 * 1.02) ** -l for l in range(4)], rtol=0, atol=1e-15)
+    assert s._window(120, 151) and s.adapt_after_window(9) and abs(s.dTlog - 1.5 * 1.02 * 0.98) < 1e-15
+    assert s._window(50, 151) and not s.adapt_after_window(11)   # 0.33: inside [0.2, 0.5], the ladder stays
+    assert [h[0] for h in s.ladder_history] == [7, 9, 11]
+
+
+def test_ladder_adaptation_is_an_option_and_only_acts_in_burnin():
+    """Every closed window of the burn-in applies the rule to the rate it measured; nothing moves after the burn-in, nor
+    without the option."""
+    pr = T.Prior(kmin=1, kmax=3)
+    runs = {}
+    for adapt in (False, True):
+        s = T.Sampler(pr, ToyEvaluator(), ndata=20, nchains_total=6, nptchains1=1, dTlog=1.05, seed=5, adapt_ladder=adapt,
+                      acceptance_window=20)
+        s.init_from_prior()
+        s.run(80, burnin=50)
+        runs[adapt] = s
+    assert runs[False].dTlog == 1.05 and len(runs[False].ladder_history) == 0
+    a = runs[True]
+    # 5 neighbour pairs -> 3 or 2 proposals per round: a window (more than 20 proposals) closes every 9th round or so
+    assert len(a.ladder_history) >= 3 and all(sw < 50 for sw, _, _ in a.ladder_history)
+    d, moved = 1.05, 0
+    for _, rate, dt in a.ladder_history:
+        d = d * (1.02 if rate < 0.2 else 1.0) * (0.98 if rate > 0.5 else 1.0)
+        moved += rate < 0.2 or rate > 0.5
+        assert abs(dt - d) < 1e-15
+    assert moved >= 1 and a.dTlog == d   # a ladder this narrow exchanges nearly always: the rule narrows it further (x 0.98 above 0.5)
+    assert np.allclose(a.beta_of_level, [a.dTlog ** -l for l in range(len(a.beta_of_level))], rtol=0, atol=1e-15)
+
+
 class NanForFastTopEvaluator:
     """NaN residual sum for every model whose shallowest node is faster than 6000 m/s (NaN data / an unusable model row)."""
     def __call__(self, node_sets):
@@ -801,3 +840,44 @@ def test_device_sampler_keeps_a_sentinel_residual_finite(golden_batches):
     h.run(5, 0, None, 0)                                                  # and the chains can move: ratios are finite numbers
     assert np.all(np.isfinite(h.get_all()["logL"]))
     assert rt.load_library().rtmi_device_status() == 0
+
+
+@pytest.mark.gpu
+def test_native_burnin_ladder_adaptation(kat):
+    """The opt-in burn-in re-spacing of the ladder through the device sampler: the rule is applied between pieces of the
+    burn-in of one acceptance window each (rtmi_pt_set_ladder_betas keeps levels, counters and the exchange's stream), the
+    chains' betas on the device follow the new ladder, logL bookkeeping stays the oracle's, and a run without the option is
+    untouched by the new code (bit-equal to a run of the same seed that never heard of it)."""
+    from oracle import oracle as O
+    m = kat["model"]
+    off, dep, obs = kat["test_1_src_offset"], kat["test_1_src_depth"], kat["test_1_obs_RT"]
+    start = np.column_stack([[0.0] + m["depths"], m["vels"]])
+
+    def run(adapt):
+        ev = T.GpuEvaluator(off, dep, obs)
+        s = T.NativeSampler(T.Prior(), ev, ndata=20, nchains_total=8, nptchains1=1, dTlog=3.0, seed=4, adapt_ladder=adapt,
+                            acceptance_window=30)
+        s.init_from_model(start, 0.02)
+        samples = s.run(400, burnin=300)
+        s.sync()
+        return s, samples
+
+    s0, smp0 = run(False)
+    s1, smp1 = run(True)
+    assert s0.dTlog == 3.0 and s0.ladder_history == []
+    # dTlog = 3 spaces the ladder so widely that few exchanges are accepted: the reference's rule then WIDENS it further
+    # (x 1.02 below 0.2 -- its direction, kept); whichever way, every recorded step follows the rule from the recorded rate
+    assert len(s1.ladder_history) >= 5 and all(sw < 300 for sw, _, _ in s1.ladder_history)
+    d = 3.0
+    for _, rate, dt in s1.ladder_history:
+        d = d * (1.02 if rate < 0.2 else 1.0) * (0.98 if rate > 0.5 else 1.0)
+        assert abs(dt - d) < 1e-12
+    assert s1.dTlog != 3.0
+    lev, _, _ = s1.native.get_ladder()
+    beta_dev = s1.native.get_all()["beta"]
+    assert np.allclose(beta_dev, [s1.dTlog ** -float(lev[s1.first + i]) for i in range(s1.nloc)], rtol=0, atol=1e-15)
+    assert len(smp0) == len(smp1) == 100
+    for c in s1.chains:
+        v, z = T.layering(c.nodes)
+        ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v, z, off, dep), c.sd, stable=True)
+        assert abs(c.logL - ref) <= 1e-9 * max(1.0, abs(ref))
