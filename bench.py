@@ -492,6 +492,12 @@ def run_pt(rt, torch, dist, rank, world, dev, nsrc, kmax, steps, warmup):
             for _ in range(n):
                 s.sweep()
                 s.swap_round()
+    # Setup, untimed: a handle chooses its sweep engine by a timed trial in its first long call (ten sweeps, half of them on the
+    # engine it may then discard, once the sweeps have their full length: rtmi_pt_run) -- that belongs to creating the handle,
+    # like capturing a graph, not to the K steps this bench times.
+    settle = kmax + 22
+    if device_loop:
+        run_steps(settle)
     run_steps(warmup)
     st0 = s.native.stats()
     tr0, ca0 = s.native.likelihood_counts()
@@ -508,12 +514,14 @@ def run_pt(rt, torch, dist, rank, world, dev, nsrc, kmax, steps, warmup):
         dist.all_reduce(tm)
         tot = tm.cpu().numpy()
     launches = st1["launches"] - st0["launches"]
-    engine = ("one persistent cooperative launch per sweep" if launches <= 2 * max(1, steps)
-              else "two launches per proposal slot / pass, replayed as a hipGraph")
+    eng = sp1["engine"]   # what the handle runs: 1 persistent, 0 per-slot launches, -1 still undecided (no long call yet)
+    engine = ("one persistent cooperative launch per sweep" if eng == 1 else
+              ("two launches per proposal slot / pass, replayed as a hipGraph" if eng == 0 or launches > 2 * max(1, steps)
+               else "undecided (per-slot launches so far)"))
     exchange = ("RCCL all-gather of 8 B per chain (rtmi_pt_swap_round)" if s.comm is not None
                 else ("every chain local: no collective" if world == 1 else "host gather (gloo rehearsal)"))
     return {"elapsed": elapsed, "models": float(tot[0]), "traced": float(tot[1]), "cached": float(tot[2]), "discarded": float(tot[3]),
-            "launches": launches, "engine": engine, "exchange": exchange, "level": s.level, "nloc": nloc, "speculation_rows": sp1["rows"],
+            "launches": launches, "engine": engine, "engine_trial_sweeps": settle if device_loop else 0, "exchange": exchange, "level": s.level, "nloc": nloc, "speculation_rows": sp1["rows"],
             "rccl_ranks": s.comm.size() if s.comm is not None else 1, "swap_accept_rate": s.stats["acc_swap"] / max(1, s.stats["prop_swap"]),
             "red_device": red}
 
@@ -539,6 +547,7 @@ def bench_pt(args, rt, torch, dist, rank, world, dev):
                           "chains": r["nloc"] * world, "models_decided": models, "models_evaluated_and_discarded": r["discarded"],
                           "speculation_rows_per_chain": r["speculation_rows"],
                           "launches_per_step": r["launches"] / max(1, args.steps),
+                          "engine_trial_sweeps_before_warmup": r["engine_trial_sweeps"],
                           "engine": "device-resident sweep (rtmi_pt_run), " + r["engine"] + ", swap exchange: " + r["exchange"],
                           "swap_accept_rate": r["swap_accept_rate"],
                           "sources_retraced_fraction": (r["traced"] / seen) if seen > 0 else 1.0,

@@ -18,7 +18,7 @@
 // reference (which stops 0.1 m short of the root): median 2.4e-7 s, 99.9th percentile 3.4e-5 s = the reference's own
 // stopping tolerance (tests/test_gpu_f32fast.py).
 //
-// Machine mapping: persistent workgroups of 256 lanes; per tile of 1024 sources a counting sort by source layer in LDS (so
+// Machine mapping: persistent workgroups of 256 lanes; per tile of up to 1280 sources a counting sort by source layer in LDS (so
 // that the 64 lanes of a wave walk the same number of layers), one source per lane, the per-stack coefficient rows stored
 // as PAIRS of layers -- {c_i, c_i+1, (H r)_i, (H r)_i+1} and {(H / V)_i, (H / V)_i+1} -- so that one ds_read_b128 (broadcast when
 // the wave shares a row) feeds two layer terms and the arithmetic on them is packed (v_pk_fma_f32 / v_pk_mul_f32 /
@@ -35,7 +35,11 @@ namespace rtmi {
 
 #define F32F_BLOCK 256
 #ifndef F32F_PER_THREAD
-#define F32F_PER_THREAD 4  // tiles of 1024 sources: four workgroups (16 waves) per CU; tiles of 2048 (three workgroups) were 12 % slower
+// tiles of up to 1280 sources, four workgroups (16 waves) per CU.  Measured (profiles/r04q/f32fast_tile.txt, one box): at config
+// 5's per-GPU share a workgroup's slice is 1221 sources -- ONE tile of five per lane (0.0373 ms) instead of two of 640 with four
+// per lane (0.0421) or six (0.0402); at 1e7 sources 0.2244 / 0.2271 / 0.2220.  Tiles of 2048 (three workgroups per CU) were 12 %
+// slower in round 3.
+#define F32F_PER_THREAD 5
 #endif
 #define F32F_TILE (F32F_BLOCK * F32F_PER_THREAD)
 #define F32F_MAXIT 12
@@ -118,9 +122,11 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     // per layer and per stack height, one lane each: the divisions of the whole staging (the pairs below only multiply)
     auto thick = [&](int i) { return i == 0 ? (double)D[0] : (double)D[i] - (double)D[i - 1]; };
     for (int il = threadIdx.x; il < W; il += F32F_BLOCK) {
-        double m = (double)Vs[0];
+        float mf = Vs[0];  // (the maximum of floats is a float: no rounding in either precision)
+#pragma unroll 4
         for (int i = 1; i <= il; ++i)
-            m = fmax(m, (double)Vs[i]);
+            mf = fmaxf(mf, Vs[i]);
+        const double m = (double)mf;
         const double im = 1.0 / m, vl = (double)Vs[il];
         vmaxd[il] = m;
         ivm[il] = im;
@@ -131,55 +137,67 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
     }
     __syncthreads();
     F32F_STAMP(6);
-    // One row (stack) per group of 32 lanes, a layer of it per lane: the table entries and the three sums over the stack that
-    // the start values need, the sums by a fixed tree over the group (the same bits on every launch).  [Round 3 had one
-    // LANE per row walk its layers with three double-precision divides and a square root per layer, and every workgroup --
-    // four per CU, on the same vector units -- does this before its first source: 10 us of a 44 us launch at config 5's
-    // per-GPU share (profiles/r04m/f32fast_phases.txt).  Here a pair (stack, layer) costs a dozen multiplications: the
-    // reciprocals are per stack / per layer (above), and the saturated offset's 1 / sqrt(c) is needed to 1e-6 only (the
-    // start value it bounds carries that margin), so the single-precision v_rsq_f32 serves.]
+    // The table entries, one (stack, layer) pair per lane, and the three sums over the stack that the start values need: the
+    // pairs leave their addends in LDS (the tiles' staging area is free until the first tile), then one lane per stack adds
+    // them in layer order (the same bits on every launch).  [Round 3 had one LANE per stack walk its layers with three
+    // double-precision divides and a square root per layer, and every workgroup -- four per CU, on the same vector units --
+    // does this before its first source: 10 us of a 44 us launch at config 5's per-GPU share
+    // (profiles/r04m/f32fast_phases.txt).  Here a pair costs a dozen multiplications: the reciprocals are per stack / per
+    // layer (above), and the saturated offset's 1 / sqrt(c) is needed to 1e-6 only (the start value it bounds carries that
+    // margin), so the single-precision v_rsq_f32 serves.]
     {
         float *fa = reinterpret_cast<float *>(tabA);
         float *fb = reinterpret_cast<float *>(tabB);
-        const int g = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-        for (int il = g; il < W; il += F32F_BLOCK / 32) {
-            const double vm = vmaxd[il], im = ivm[il], im2 = ivm2[il];
-            double afull = 0.0, hc = 0.0, binf = 0.0;
-            for (int i = l32; i < WS; i += 32) {
+        double2 *addend = reinterpret_cast<double2 *>(sz);  // [rows of a batch][WS] {H r, H r / sqrt(c) or -(H r) for a fastest layer}: over sz, sR (the velocities sit in tout)
+        const int rows_per_batch = (int)((size_t)2 * F32F_TILE * sizeof(float) / ((size_t)WS * sizeof(double2)));  // >= 8 (W <= 64)
+        for (int r0 = 0; r0 < W; r0 += rows_per_batch) {
+            const int nr = W - r0 < rows_per_batch ? W - r0 : rows_per_batch;
+            for (int e = threadIdx.x; e < nr * WS; e += F32F_BLOCK) {
+                const int il = r0 + e / WS, i = e % WS;
                 float c = 0.0f, hr = 0.0f, hv = 0.0f;
+                double2 ad = make_double2(0.0, 0.0);
                 if (i < il) {
-                    const double vi = (double)Vs[i], ai = thick(i) * (vi * im);
-                    c = (float)(((vm - vi) * (vm + vi)) * im2);
+                    const double vm = vmaxd[il], vi = (double)Vs[i], ai = thick(i) * (vi * ivm[il]);
+                    c = (float)(((vm - vi) * (vm + vi)) * ivm2[il]);
                     hr = (float)ai;
                     hv = (float)hvd[i];
-                    afull += ai;
-                    if (c > 0.0f)
-                        binf += ai * (double)__builtin_amdgcn_rsqf(c);
-                    else
-                        hc += ai;
+                    ad.x = ai;
+                    ad.y = c > 0.0f ? ai * (double)__builtin_amdgcn_rsqf(c) : -ai;
                 }
                 const int pr = il * WH + (i >> 1), hf = i & 1;
                 fa[4 * pr + hf] = c;
                 fa[4 * pr + 2 + hf] = hr;
                 fb[2 * pr + hf] = hv;
+                addend[e] = ad;
             }
+            __syncthreads();
+            for (int r = threadIdx.x; r < nr; r += F32F_BLOCK) {
+                const int il = r0 + r;
+                double afull = 0.0, hc = 0.0, binf = 0.0;
+                // (over the whole row, four entries a trip, so that the reads are in flight together: the addends from layer il
+                // on are {0, 0}, and x + 0 = x)
+                for (int i = 0; i < WS; i += 4) {
+                    double2 ad[4];
 #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {  // stays inside the group of 32
-                afull += __shfl_xor(afull, off, 64);
-                hc += __shfl_xor(hc, off, 64);
-                binf += __shfl_xor(binf, off, 64);
-            }
-            if (l32 == 0) {
-                const double vl = (double)Vs[il];
-                const float cl = (float)(((vm - vl) * (vm + vl)) * im2);
-                diag[il] = make_float4(cl, (float)(vl * im), (float)ivl[il], (float)afull);
+                    for (int u = 0; u < 4; ++u)
+                        ad[u] = addend[r * WS + i + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        afull += ad[u].x;
+                        binf += ad[u].y >= 0.0 ? ad[u].y : 0.0;
+                        hc -= ad[u].y >= 0.0 ? 0.0 : ad[u].y;
+                    }
+                }
+                const double vm = vmaxd[il], vl = (double)Vs[il];
+                const float cl = (float)(((vm - vl) * (vm + vl)) * ivm2[il]);
+                diag[il] = make_float4(cl, (float)(vl * ivm[il]), (float)ivl[il], (float)afull);
                 // rounded so that the start value stays a LOWER bound of the root: hc up, the saturated offset up (the margin
                 // covers v_rsq_f32's 1e-7)
                 diag2[il] = make_float4((float)(hc * (1.0 + 1e-6)), (float)(binf * (1.0 + 2e-6)), cl > 0.0f ? (float)(1.0 / sqrt((double)cl)) : 0.0f, 0.0f);
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
 
     F32F_STAMP(0);  // the model's tables
     const int lane = threadIdx.x & 63;

@@ -2077,6 +2077,9 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
     return e;
 }
 
+#ifndef RTMI_PT_TEAMS_DEFAULT
+#define RTMI_PT_TEAMS_DEFAULT 1
+#endif
 extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtSweepArgs *d_w,
                                           int nspec, unsigned int epoch, int parity, int nslots_k, int nchains, int max_nlayers,
                                           int num_cus, int waves_per_simd, hipStream_t stream)
@@ -2101,6 +2104,24 @@ extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const voi
     size_t lds_bytes = 0;
     int threads = 0;
     (void)rtmi_fused_geometry(a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads, &a.slots, &lds_bytes);
+    // RTMI_PT_TEAMS=2: two workgroups of half the size per CU.  A chain's workgroups idle while its leading workgroup takes
+    // the step (a quarter of a pass); with two workgroups of different chains on a CU the other one's likelihood share runs
+    // in that time.  Same waves per SIMD, half the record area each.
+    static const int teams = getenv("RTMI_PT_TEAMS") ? atoi(getenv("RTMI_PT_TEAMS")) : RTMI_PT_TEAMS_DEFAULT;
+    int nwg = num_cus;
+    if (teams == 2 && threads >= 256 && 2 * nchains <= 2 * num_cus) {
+        const size_t slot_bytes = (size_t)3 * sizeof(double) + 10;
+        const size_t fixed = lds_bytes - (size_t)a.slots * slot_bytes;
+        const size_t share = (size_t)80 * 1024 - 4 * PROP_WORDS - 64 - 16 - 512;  // (512: the kernel's static LDS, generously)
+        if (share > fixed + 64 * slot_bytes) {
+            const int max_slots = (int)((share - fixed) / slot_bytes / 64 * 64);
+            threads /= 2;
+            if (a.slots > max_slots)
+                a.slots = max_slots;
+            lds_bytes = fixed + (size_t)a.slots * slot_bytes;
+            nwg = 2 * num_cus;
+        }
+    }
     int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);
     lds_bytes = (size_t)lds_ctl + 4 * PROP_WORDS + 64;  // + the kernel's control words and its diagnostic sums
     if (lds_bytes > 160 * 1024 || threads < 64)
@@ -2113,7 +2134,7 @@ extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const voi
         return e;
     int max_pass = 2 * nslots_k + 2;  // a pass retires at least one slot of the chain
     void *kargs[7] = {&a, &dp, &d_w, &epoch, &parity, &max_pass, &lds_ctl};
-    return hipLaunchCooperativeKernel(fn, dim3((unsigned)num_cus), dim3((unsigned)threads), kargs, lds_bytes, stream);
+    return hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3((unsigned)threads), kargs, lds_bytes, stream);
 }
 
 extern "C" hipError_t rtmi_launch_fused_f32(const rtmi::FusedArgsT<float> *args, int nmodels, int max_nlayers,
