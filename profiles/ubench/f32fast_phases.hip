@@ -2,6 +2,7 @@
 // source compiled with F32F_CLOCKS (wave 0 of every workgroup adds the cycles of each phase to a device array), driven with
 // sources like profiles/f32fast_bench.py's.  Prints the launch time by events and the phase shares.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DF32F_CLOCKS -o f32fast_phases profiles/ubench/f32fast_phases.hip
+// Without -DF32F_CLOCKS: the plain kernel (for rocprofv3 --pmc runs of this binary); -DF32F_NO_SOLVE: without its layer loops.
 #include "../../raytracerfortran_amd/csrc/rtmi_f32fast.hip"
 #include <vector>
 #include <algorithm>
@@ -35,8 +36,10 @@ int main(int argc, char **argv)
     for (int i = 0; i < 5; ++i)
         rtmi_launch_f32fast(&a, cus, 0);
     hipDeviceSynchronize();
+#ifdef F32F_CLOCKS
     static unsigned long long raw[8 * 1024];
     hipMemcpyToSymbol(HIP_SYMBOL(rtmi::f32f_clk), raw, sizeof raw);
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 20;
     hipEventRecord(e0, 0);
@@ -45,19 +48,26 @@ int main(int argc, char **argv)
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long clk[8] = {0};
+#ifdef F32F_CLOCKS
     hipMemcpyFromSymbol(raw, HIP_SYMBOL(rtmi::f32f_clk), sizeof raw);
     for (int b = 0; b < 1024; ++b)
         for (int i = 0; i < 7; ++i)
             clk[i] += raw[b * 8 + i];
+#endif
     const int64_t ntiles = (n + F32F_TILE - 1) / F32F_TILE;
     const int64_t grid = std::min<int64_t>((int64_t)cus * 4, ntiles);
     const char *names[7] = {"model tables: pairs + sums", "load sources", "locate + count + sort", "solve (wave 0)", "wait for the other waves", "store", "model tables: load, check, per layer"};
     double tot = 0;
     for (int i = 0; i < 7; ++i) tot += (double)clk[i];
-    printf("%lld sources x %d interfaces: %.4f ms per launch (%.3e travel times/s), %lld workgroups; clock64 ticks per workgroup and launch:\n",
-           (long long)n, NL, ms / reps, n / (ms / reps) * 1e3, (long long)grid);
+    printf("%lld sources x %d interfaces: %.4f ms per launch (%.3e travel times/s), %lld workgroups\n", (long long)n, NL, ms / reps,
+           n / (ms / reps) * 1e3, (long long)grid);
+#ifdef F32F_CLOCKS
+    printf("clock64 ticks per workgroup and launch:\n");
     for (int i = 0; i < 7; ++i)
         printf("  %-38s %9.0f  %5.1f %%\n", names[i], (double)clk[i] / reps / grid, 100.0 * clk[i] / tot);
     printf("  %-38s %9.0f  (= the launch's %.1f us if a workgroup lives as long as the launch: %.2f GHz)\n", "sum", tot / reps / grid, ms / reps * 1e3, tot / reps / grid / (ms / reps * 1e6));
+#else
+    (void)names; (void)tot;
+#endif
     return 0;
 }

@@ -298,7 +298,11 @@ __global__ __launch_bounds__(F32F_BLOCK) void f32fast_kernel(F32FastArgs a)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
                 ilv = max(ilv, __shfl_xor(ilv, off, 64));
+#ifdef F32F_NO_SOLVE  // (profiles/ubench/f32fast_phases.hip: the kernel without its layer loops, to tell whose LDS traffic the counters show)
+            const int ilw = 0;
+#else
             const int ilw = __builtin_amdgcn_readfirstlane(ilv);  // the wave's deepest stack, as a scalar
+#endif
             if (ilw == 0) {
                 tt = __builtin_sqrtf(zq * zq + Rq * Rq) * diag[0].z;  // top layer (:94-97): t = sqrt(z^2 + R^2) / v_1
             } else {

@@ -2078,7 +2078,7 @@ extern "C" hipError_t rtmi_launch_pt_sweep(const rtmi::FusedArgs *args, const vo
 }
 
 #ifndef RTMI_PT_TEAMS_DEFAULT
-#define RTMI_PT_TEAMS_DEFAULT 1
+#define RTMI_PT_TEAMS_DEFAULT 2  // with four rows per chain (see rtmi_launch_pt_prop); profiles/r04r/pt_teams.txt
 #endif
 extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const void *ptdev, size_t ptdev_bytes, const rtmi::PtSweepArgs *d_w,
                                           int nspec, unsigned int epoch, int parity, int nslots_k, int nchains, int max_nlayers,
@@ -2104,22 +2104,26 @@ extern "C" hipError_t rtmi_launch_pt_prop(const rtmi::FusedArgs *args, const voi
     size_t lds_bytes = 0;
     int threads = 0;
     (void)rtmi_fused_geometry(a.nsrc, max_nlayers, num_cus, num_cus, waves_per_simd, (int)sizeof(double), &threads, &a.slots, &lds_bytes);
-    // RTMI_PT_TEAMS=2: two workgroups of half the size per CU.  A chain's workgroups idle while its leading workgroup takes
-    // the step (a quarter of a pass); with two workgroups of different chains on a CU the other one's likelihood share runs
-    // in that time.  Same waves per SIMD, half the record area each.
-    static const int teams = getenv("RTMI_PT_TEAMS") ? atoi(getenv("RTMI_PT_TEAMS")) : RTMI_PT_TEAMS_DEFAULT;
+    // Two workgroups of half the size per CU (RTMI_PT_TEAMS=2; the default with four rows per chain).  A chain's workgroups idle
+    // while its leading workgroup takes the step (a quarter of a pass) and while the slowest of them finishes its share; with
+    // workgroups of different chains on a CU the other one's likelihood share runs in that time.  Same waves per SIMD, half the
+    // record area each.  Measured on config 3's shape (profiles/r04r, r04s/pt_teams.txt): three rows 0.776 -> 0.774 ms per sweep,
+    // four rows 0.787 -> 0.742; four workgroups of 256 lanes per CU are refused by the cooperative launch.
+    static const int teams_env = getenv("RTMI_PT_TEAMS") ? atoi(getenv("RTMI_PT_TEAMS")) : 0;
+    int teams = teams_env > 0 ? teams_env : (nspec >= 4 ? RTMI_PT_TEAMS_DEFAULT : 1);
+    teams = teams >= 2 && threads >= 512 ? 2 : 1;
     int nwg = num_cus;
-    if (teams == 2 && threads >= 256 && 2 * nchains <= 2 * num_cus) {
+    if (teams > 1) {
         const size_t slot_bytes = (size_t)3 * sizeof(double) + 10;
         const size_t fixed = lds_bytes - (size_t)a.slots * slot_bytes;
-        const size_t share = (size_t)80 * 1024 - 4 * PROP_WORDS - 64 - 16 - 512;  // (512: the kernel's static LDS, generously)
+        const size_t share = (size_t)160 * 1024 / teams - 4 * PROP_WORDS - 64 - 16 - 512;  // (512: the kernel's static LDS, generously)
         if (share > fixed + 64 * slot_bytes) {
             const int max_slots = (int)((share - fixed) / slot_bytes / 64 * 64);
-            threads /= 2;
+            threads /= teams;
             if (a.slots > max_slots)
                 a.slots = max_slots;
             lds_bytes = fixed + (size_t)a.slots * slot_bytes;
-            nwg = 2 * num_cus;
+            nwg = teams * num_cus;
         }
     }
     int lds_ctl = (int)((lds_bytes + 15) / 16 * 16);

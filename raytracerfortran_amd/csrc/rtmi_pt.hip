@@ -548,12 +548,13 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     // a chain is bit for bit the chain of the one-at-a-time step.  RTMI_PT_SPECULATE = rows per chain (0: the one-at-a-time
     // step pt_step_group).
     // Default: speculate where a pass is bound by the LATENCY of a likelihood evaluation -- a chain's workgroups hold a
-    // couple of records per lane or fewer (BASELINE config 3: 1e4 sources over 8 workgroups; 0.92 -> 0.78 ms per sweep,
-    // profiles/r04c/pt_timings.txt) -- and not where it is bound by throughput (config 4's share, 1e5 sources per chain:
-    // every speculated model that is thrown away is work the machine had no room for, 3.07 -> 3.97 ms).  Rows per chain = what
-    // one round of the step's lane groups takes (K <= 16: four groups, three rows measured best; K <= 32: two).
+    // couple of records per lane or fewer (BASELINE config 3: 1e4 sources over 8 workgroups; 0.92 -> 0.74 ms per sweep,
+    // profiles/r04c/pt_timings.txt, r04s/pt_teams.txt) -- and not where it is bound by throughput (config 4's share, 1e5 sources
+    // per chain: every speculated model that is thrown away is work the machine had no room for, 3.07 -> 3.97 ms).  Rows per
+    // chain = what one round of the step's lane groups takes (K <= 16: four groups -- four rows, on two workgroups of 512 lanes
+    // per CU, rtmi_launch_pt_prop; with one workgroup of 1024 per CU three rows measured best; K <= 32: two).
     const int gx0 = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
-    int want_spec = (c.set_n / (gx0 > 0 ? gx0 : 1) <= RTMI_PT_SPECULATE_MAX_SHARE) ? (prior->kmax <= 16 ? 3 : 2) : 0;
+    int want_spec = (c.set_n / (gx0 > 0 ? gx0 : 1) <= RTMI_PT_SPECULATE_MAX_SHARE) ? (prior->kmax <= 16 ? 4 : 2) : 0;
     if (const char *e = getenv("RTMI_PT_SPECULATE"))
         want_spec = atoi(e);
     if (want_spec > PT_SPEC_MAX)
