@@ -154,6 +154,10 @@ int rtmi_pt_sweep(rtmi_pt *h, int nsweeps);   /* = rtmi_pt_run(h, nsweeps, 0, NU
 /* out8: accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, likelihood launches,
  * models evaluated */
 int rtmi_pt_stats(const rtmi_pt *h, int64_t *out8);
+/* the same counters chain by chain (the reference keeps them per chain object: obj%iaccept_bd ..., prjmh_temper_rf.f90:1880-1883):
+ * out[nchains][8] = accepted/proposed birth-death, accepted/proposed perturbations, accepted/proposed sigma, models of the
+ * chain that went through the likelihood and were decided, speculated models evaluated and then discarded */
+int rtmi_pt_chain_stats(const rtmi_pt *h, int64_t *out);
 /* incremental likelihood: sources of proposals traced / taken from the residual cache so far */
 int rtmi_pt_likelihood_counts(const rtmi_pt *h, int64_t *traced, int64_t *cached);
 /* position of every chain's counter-based random stream (draws taken so far), ctr[nchains]: part of a chain's state --

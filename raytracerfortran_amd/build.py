@@ -25,8 +25,14 @@ HEADERS = [os.path.join(CSRC, h) for h in ("rtmi_kernels.h", "rtmi_device.hpp", 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
 OBJDIR = os.path.join(CSRC, "build")
+# -enable-ipra=false: the persistent sweep kernels (rtmi_kernels.hip) make REAL calls (the sampler's step, the hand-shakes) from
+# wave 0 of a chain's leading workgroup only.  With inter-procedural register allocation the caller keeps values in registers the
+# callee is known not to touch; round 4 met a build in which the residual sums of the chains whose leading workgroup is the first
+# of an XCD came out 1e-6 off and different from run to run -- only in a process that had run the other instantiation of the
+# kernel in between (registers hold whatever the previous kernel left), reproduced by profiles/dbg_spec3.py, gone with the
+# calling convention taken at its word.  No kernel of the forward path makes a call: C2 and the batch kernels are unaffected.
 CFLAGS = ["-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall",
-          "-Wno-unused-result"]
+          "-Wno-unused-result", "-mllvm", "-enable-ipra=false"] + os.environ.get("RTMI_EXTRA_CFLAGS", "").split()
 LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}"]
 ROCM_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
 LIBS = [f"-L{ROCM_LIB}", "-lrccl", "-lpthread"]

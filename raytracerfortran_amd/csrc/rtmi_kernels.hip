@@ -1490,6 +1490,11 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
         dg[0] = dg[1] = dg[2] = dg[3] = dg[4] = 0ull;
         dg[5] = __builtin_amdgcn_s_memrealtime();
     }
+    if (wp->xcd_map == 77) {  // (diagnostic, RTMI_PT_POISON_LDS: what the likelihood body reads of LDS it has not written shows up as NaN)
+        for (int q = threadIdx.x; q < lds_ctl / 8; q += blockDim.x)
+            reinterpret_cast<unsigned long long *>(lds_raw)[q] = 0x7FF8DEADBEEF0000ull + (unsigned)q;
+        __syncthreads();
+    }
     if (threadIdx.x < 64)
         prop_layout(wp, parity, ctl);
     __syncthreads();
@@ -1525,7 +1530,15 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
                 __hip_atomic_fetch_add(st + 2, dg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(st + 3, dg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(st + 4, dg[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(st + 5, __builtin_amdgcn_s_memrealtime() - dg[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long life = __builtin_amdgcn_s_memrealtime() - dg[5];
+                __hip_atomic_fetch_add(st + 5, life, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ctl[PROP_ROW] == 0) {  // per chain (its leading workgroup): ticks, sweeps, the longest, passes
+                    unsigned long long *q = st + 8 + 4 * (size_t)ctl[PROP_CHAIN];
+                    q[0] += life;
+                    q[1] += 1ull;
+                    q[2] = life > q[2] ? life : q[2];
+                    q[3] += dg[3];
+                }
             }
             return;
         }

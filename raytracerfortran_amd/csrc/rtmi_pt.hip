@@ -108,6 +108,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_pack_current_kernel(PtDev d)
         d.nact[c] = 1;
         d.wend[c] = 0;
         d.winv[c] = 0;
+        d.pend_i[4 * c + 2] = 0;
+        d.pslot[m] = 0;
         d.alist[m] = 0;
         d.rowwg[m] = d.gx_launch;
         o->pending = d.pend_i[4 * c + 0];
@@ -566,7 +568,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     const int gx = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);     // workgroups per CHAIN (persistent engine)
     h->gx_launch = batch_grid_x(h->nrows, h->max_nl, c.set_n, c.cus);    // workgroups per ROW of the batched launch
     const int pstride = gx > h->gx_launch ? gx : h->gx_launch;  // (with the speculative step a row's sums are ONE accumulator)
-    const size_t nf64 = 2 * nc * K + 2 * nr * K + 4 * nc + nr + 2 * nr * ldm;
+    const size_t nf64 = 4 * nc * K + 2 * nr * K + 4 * nc + nr + 2 * nr * ldm;
     const size_t ni32 = nc + 3 * nr;
     const size_t nsi32 = 11 * nc + 4 * nr, nsu64 = nc + nr;
     const int ncdf = 4096;
@@ -612,8 +614,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         ok = hipMemcpy(h->d_walloc, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok && h->spec && getenv("RTMI_PT_QSTATS"))  // diagnostic: where the workgroups' time goes (printed by rtmi_pt_run)
-        ok = hipMalloc((void **)&h->d_qstats, 8 * sizeof(unsigned long long)) == hipSuccess &&
-             hipMemset(h->d_qstats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
+        ok = hipMalloc((void **)&h->d_qstats, (8 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess &&   // + per chain: ticks, sweeps, longest, passes
+             hipMemset(h->d_qstats, 0, (8 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         rtmi::PtSweepArgs w;
         memset(&w, 0, sizeof w);
@@ -624,6 +626,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         w.nspec = h->nspec;
         w.walloc = h->d_walloc;
         w.stats = h->d_qstats;
+        w.xcd_map = getenv("RTMI_PT_POISON_LDS") ? 77 : 0;  // (diagnostic: pt_sweep_prop_kernel fills its LDS with NaN patterns first)
         ok = hipMalloc((void **)&h->d_wprop, sizeof w) == hipSuccess && hipMemcpy(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok)
@@ -721,6 +724,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.ncdf = ncdf;
     d.nspec = h->nspec;
     d.spec_step = h->spec ? 1 : 0;
+    d.spec_prop = (getenv("RTMI_PT_SPEC_PROP") ? atoi(getenv("RTMI_PT_SPEC_PROP")) : 0) ? 1 : 0;
     d.part_stride = pstride;
     d.gx_launch = h->gx_launch;
     if (ok) {
@@ -736,6 +740,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.plp = f, f += nr;
         d.V = f, f += nr * ldm;
         d.D = f, f += nr * ldm;
+        d.wz = f, f += nc * K;
+        d.wv = f, f += nc * K;
         int *i = h->d_i32;
         d.k = i, i += nc;
         d.pk = i, i += nr;
@@ -763,7 +769,6 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         d.alist = q, q += nr;
         d.wctr = h->d_spec_u64;
         d.pctr = h->d_spec_u64 + nc;
-        d.pend_z = h->d_pend_z;
         d.pinfo = h->d_pinfo;
         d.walloc = h->d_walloc;
         d.acc = h->d_partial_x;
@@ -1219,9 +1224,27 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     }
     const int rc = finish(h);  // the one synchronisation of the call
     if (!rc && h->d_qstats) {
-        unsigned long long st[8];
-        HIP_TRY(hipMemcpy(st, h->d_qstats, sizeof st, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(h->d_qstats, 0, sizeof st));
+        std::vector<unsigned long long> stv(8 + 4 * (size_t)h->nchains);
+        unsigned long long *st = stv.data();
+        HIP_TRY(hipMemcpy(st, h->d_qstats, stv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(h->d_qstats, 0, stv.size() * sizeof(unsigned long long)));
+        if (st[5] > 0 && getenv("RTMI_PT_QSTATS") && atoi(getenv("RTMI_PT_QSTATS")) >= 2) {
+            // how long the chains' sweeps take (their leading workgroups, kernel entry to the end of the chain's sweep)
+            std::vector<double> beta(h->nchains);
+            std::vector<int> kk(h->nchains);
+            HIP_TRY(hipMemcpy(beta.data(), h->d.beta, beta.size() * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(kk.data(), h->d.k, kk.size() * sizeof(int), hipMemcpyDeviceToHost));
+            double mean_all = 0.0, mean_max = 0.0;
+            for (int c = 0; c < h->nchains; ++c) {
+                const unsigned long long *q = st + 8 + 4 * (size_t)c;
+                const double m = q[1] ? 0.01 * (double)q[0] / (double)q[1] : 0.0;
+                mean_all += m / h->nchains;
+                mean_max = m > mean_max ? m : mean_max;
+                fprintf(stderr, "rtmi:   chain %2d beta %.4f k %2d: sweep %.0f us on average, longest %.0f us, %.2f passes per sweep\n", c, beta[c], kk[c], m,
+                        0.01 * (double)q[2], q[1] ? (double)q[3] / (double)q[1] : 0.0);
+            }
+            fprintf(stderr, "rtmi:   mean over the chains %.0f us, slowest chain on average %.0f us\n", mean_all, mean_max);
+        }
         if (st[5] > 0)
             fprintf(stderr, "rtmi: speculative sweeps (%d): %llu likelihood shares (%.1f us each), %llu steps (%.1f us each); of the "
                             "workgroups' time %.1f %% in the likelihood, %.1f %% in steps, %.1f %% waiting\n", nsweeps, st[3],
@@ -1249,6 +1272,19 @@ int rtmi_pt_stats(const rtmi_pt *hc, int64_t *out8)
     }
     out8[6] = h->launches;
     out8[7] += h->models;  // + the models of rtmi_pt_evaluate
+    return RTMI_OK;
+}
+
+int rtmi_pt_chain_stats(const rtmi_pt *hc, int64_t *out)
+{
+    rtmi_pt *h = const_cast<rtmi_pt *>(hc);
+    if (!h || !out)
+        return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_chain_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    static_assert(sizeof(long long) == sizeof(int64_t), "stats are 64-bit counters");
+    HIP_TRY(hipMemcpy(out, h->d.stats, (size_t)h->nchains * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return RTMI_OK;
 }
 

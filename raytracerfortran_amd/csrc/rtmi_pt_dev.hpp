@@ -54,14 +54,15 @@ struct PtDev {
     // (nspec = 1: by chain, the non-speculative step).
     int nspec;
     int spec_step;        // the handle runs pt_step_spec (RTMI_PT_SPECULATE >= 1); 0 = the one-at-a-time step pt_step_group
+    int spec_prop;        // 1: a window holds rows in proportion to the chain's slots (nspec at kmax nodes), see pt_step_spec
     int part_stride;      // residual sums of row m: partial_x[(m * part_stride + j) * 4], j < rowwg[m]
     int *cur;             // [nchains] the chain's next undecided slot of the current sweep (0 = birth/death, s = (node s>>1, parameter s&1))
     int *fin;             // [nchains] the sweep's sigma move is done: nothing left to do until the next sweep
     int *nwin;            // [nchains] proposals of the window that await their decisions (entries e < nwin); -1 = no window
     int *wend;            // [nchains] the slot after the window (where the chain goes on when every entry is rejected)
     unsigned long long *wctr;  // [nchains] ... and the position of its random stream there
-    int *winv;            // [nchains] proposals outside the prior after the window's last entry: birth/death | perturbations << 8
-    int *pslot;           // [rows] the slot of entry e
+    int *winv;            // [nchains] bit j: the window's slot wbase + j drew a proposal outside the prior; slots covered << 16
+    int *pslot;           // [rows] the slot of entry e | (a trivial move was accepted on the path before it) << 16
     int *pinv;            // [rows] proposals outside the prior between the entry before and this one (same packing)
     unsigned long long *pctr;  // [rows] position of the random stream after the entry's proposal was drawn (= its acceptance draw)
     int *rowwg;           // [rows] workgroups that evaluate the row (= partial sums to add up)
@@ -69,8 +70,9 @@ struct PtDev {
     int *alist;           // [rows]   ... and which (alist[chain * nspec + a] = e of the a-th)
     int *wbuf;            // [nchains] which of the two sets of proposal rows (of the residual slab) the chain's rows write next
     // chain-level record of the pending accepted proposal: pend_i[4 c] = pending, pend_i[4 c + 1] = its PtPend record + 1
-    double *pend_z;       // (unused)
-    int *pend_i;          // [nchains][4]
+    double *wz, *wv;      // [nchains][K] the nodes at the end of the window's predicted path (pt_step_spec)
+    int *pend_i;          // [nchains][4]: + [4 c + 2] the window's trivial moves (bit j: slot wbase + j; bit 16 + j: accepted),
+                          // [4 c + 3] k at the end of the path
     rtmi::PtPend *pinfo;  // [2][nchains * nspec] what a later pass needs to know about an accepted proposal (rtmi_kernels.h)
     unsigned long long *acc;  // [rows][part_stride][4] = partial_x, writable: the step zeroes the accumulator of every row it proposes
     int gx_launch;        // per-slot engine: workgroups per row of the batched launch (rowwg of every evaluated row)
@@ -415,45 +417,56 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // =====================================================================================================================
 // The SPECULATIVE step (exact: chains advance bit for bit as with pt_step_group).
 //
-// A perturbation is accepted about one time in five, so four times in five the state after a proposal slot is the state
-// before it; and the chain's draws are indexed by (sweep, slot, purpose) (rtmi_pt_rules.h), so the proposals of the slots
-// s, s + 1, ... ASSUMING EVERY ONE OF THEM IS REJECTED are all known at once -- each is drawn from the same model with draws
-// that depend on nothing but its slot.  One step therefore proposes a WINDOW of up to `nspec` slots (one model row for
-// each proposal that falls inside the prior, m = chain * nspec + e), one likelihood pass evaluates the rows side by side,
-// and the next step takes their decisions with the very acceptance draws the one-at-a-time sampler would take: the first
-// accepted entry (in slot order) becomes the state, the entries behind it are discarded (they were drawn from a state that
-// no longer is the chain's) and the chain goes on from the slot after it; if none is accepted the whole window is retired.
-// Same draws, same sums (they are exact integers), same decisions: prjmh_temper_rf.f90:721-759 (sequential perturbations),
-// :669-713 (birth / death), :561-569 (sigma) are run as written, only the likelihoods are evaluated ahead of time.
+// The chain's draws are indexed by (sweep, slot, purpose) (rtmi_pt_rules.h), so what a chain does in the slots s, s + 1, ...
+// can be worked out ahead of the likelihoods along a PREDICTED PATH:
+//   * a proposal outside the prior is rejected whatever happens (no model row, :707-711);
+//   * a proposal that changes the model only below the deepest source ("trivial": a node down there moved, was born or
+//     died) leaves every residual, hence SS, as it is -- its acceptance ratio is the prior's alone, its acceptance draw is
+//     known, so its OUTCOME IS KNOWN when it is drawn: it is decided on the spot, and the path goes on from the state it
+//     leaves.  On BASELINE config 3 these are one slot in six, nearly all of them accepted -- three quarters of everything a
+//     cold chain accepts (profiles/r04u/acc_by_level.txt) -- and up to round 4's first form each of them ended the window;
+//   * a proposal that changes travel times needs its likelihood: it gets a model row, and the path ASSUMES IT IS REJECTED
+//     (a cold chain accepts 3 % of them, the hottest 11 %).
+// One step therefore lays out a WINDOW of up to PT_WIN_MAX slots holding up to `nspec` evaluated proposals (rows
+// m = chain * nspec + e), one likelihood pass evaluates the rows side by side, and the next step takes their decisions in
+// slot order with the very acceptance draws the one-at-a-time sampler would take: the first accepted entry becomes the
+// state (it was drawn from the path's state at its slot, so it carries the trivial moves before it), everything behind it --
+// rows, trivial moves, proposals outside the prior -- is void (drawn from a state that no longer is the chain's) and the chain
+// goes on from the slot after it; if none is accepted the state at the END of the path becomes the chain's and the whole
+// window is retired.  Same draws, same sums (they are exact integers), same decisions: prjmh_temper_rf.f90:721-759
+// (sequential perturbations), :669-713 (birth / death), :561-569 (sigma) are run as written, only the likelihoods are
+// evaluated ahead of time.  Statistics are taken when the window is decided, for the slots up to the accepted one.
 //
-// ONE WAVE PER CHAIN, THE WINDOW'S SLOTS SIDE BY SIDE: the wave's 64 lanes are 64 / G groups of G lanes (G = 16, 32, 64 >= K);
-// every group holds the chain's nodes (lane i of a group = node i) and works on a slot of its own -- group g of round r takes
-// the window's slot r (64 / G) + g: the proposal (draws, bounds, depth order, model row, what the likelihood needs to know)
-// when the window is made, the decision (likelihood, acceptance draw, ratio) when it comes back.  A proposal costs a lone
-// wave about 6 us of dependent instructions; four of them one after the other were more than the likelihood pass they
-// prepare (round 4, profiles/r04a/queue_v3_timings.txt: 77 us per step at four rows).  With K <= 16 a window of four is one
-// round; K <= 32 takes two, K <= 64 four.
+// ONE WAVE PER CHAIN, SLOTS SIDE BY SIDE: the wave's 64 lanes are 64 / G groups of G lanes (G = 16, 32, 64 >= K); every
+// group holds the path's nodes (lane i of a group = node i) and works on a slot of its own -- proposal, bounds, depth order,
+// model row when the window is made; likelihood, acceptance draw, ratio when it comes back.  A round of the groups takes the
+// next 64 / G slots from the path's state; the round is cut after the first group whose trivial move is accepted (the groups
+// behind it drew from the wrong state: they go again in the next round) and before the group that would need one row more
+// than the window has.  A proposal costs a lone wave about 6 us of dependent instructions whatever the number of groups at
+// work (profiles/r04a/queue_v3_timings.txt).
 //
 // Per chain: `cur` = its next undecided slot (0 = birth/death, s = (node s >> 1, parameter s & 1); a chain with k nodes has
-// the slots 0 .. 2k - 1, then the sigma move; slots of nodes it does not have do not exist for it), `fin` = the sweep is
-// complete.  Proposals outside the prior cost no model row; they are counted when the window is decided (winv), so that
-// the statistics are those of the one-at-a-time sampler as well.
-// Incremental likelihood: the rows of a window all read the chain's current residuals (r2cur, or the pending accepted
-// proposal's row) and write rows of their own; the two sets of proposal rows alternate whenever a proposal is accepted, so no
-// row is read and written in the same pass, and exactly one row of a pass (the first that is evaluated) moves the pending
-// residuals to r2cur.
+// the slots 0 .. 2k - 1, then the sigma move), `fin` = the sweep is complete; of the window: wend (the slot after it), winv
+// (bit j: slot wbase + j drew a proposal outside the prior; slots covered << 16), pend_i[4 c + 2] (bit j: slot wbase + j was
+// a trivial proposal; bit 16 + j: and accepted), pend_i[4 c + 3] (k at the end of the path) and wz / wv (its nodes), which
+// count only when a trivial move was accepted.  Per row: pslot = slot | (a trivial move was accepted before it) << 16.
+// Incremental likelihood: a trivial move changes no residual, so the rows of a window all read the chain's current
+// residuals (r2cur, or the pending accepted proposal's row) and write rows of their own; the two sets of proposal rows
+// alternate whenever a proposal is accepted, so no row is read and written in the same pass, and exactly one row of a pass
+// (the first) moves the pending residuals to r2cur.
 // begin: first step of a sweep.  eval: decide an evaluation of the current state (rtmi_pt_evaluate) and propose nothing.
 // wg_total: > 0 workgroups the chain's rows share in the next pass (they are dealt to the evaluated rows round-robin),
 // 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows).
 // Called by ALL 64 lanes of a wave for one chain.
-#define PT_SPEC_MAX 4
+#define PT_SPEC_MAX 8    // evaluated rows of a window
+#define PT_WIN_MAX 16    // slots of a window
 
 template <int G>
 __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const int begin, const int eval, const int wg_total)
 {
     namespace R = rtmi_pt_rules;
     constexpr int NG = 64 / G;                              // slots worked on side by side
-    constexpr int NR = (PT_SPEC_MAX + NG - 1) / NG;         // rounds a window can take
+    constexpr int NR = (PT_SPEC_MAX + NG - 1) / NG;         // rounds the decisions of a window can take
     const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
     const int i = lane - gbase;               // the node this lane holds
     const int g = lane / G;                   // this lane's group
@@ -471,6 +484,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     const int m0 = c * D;                     // the chain's first model row
     // ---- one round trip to HBM: the chain, its window, the Poisson table -----------------------------------------------
     double zi = d.z[row], vi = d.v[row];
+    const double wzi = d.wz[row], wvi = d.wv[row];  // the end of the window's path (counts when a trivial move was accepted)
     const double lpk_lo = d.logpk[i < K + 2 ? i : K + 1], lpk_hi = d.logpk[i + G < K + 2 ? i + G : K + 1];
     int k = d.k[c];
     unsigned long long nsw = d.ctr[c];        // sweeps completed: the draws are indexed by (sweep, slot, purpose)
@@ -479,8 +493,8 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     int cache_ok = d.cache_valid[c];
     int cur = begin ? 0 : d.cur[c];
     int fin = begin ? 0 : d.fin[c];
-    const int nwin = begin ? -1 : d.nwin[c];  // -1: no window awaits its decisions; 0: one without entries (its proposals outside the prior still count)
-    const int wend = d.wend[c], winv = d.winv[c];
+    const int nwin = begin ? -1 : d.nwin[c];  // -1: no window awaits its decisions; 0: one without rows (its other slots still count)
+    const int wend = d.wend[c], winv = d.winv[c], wtr = d.pend_i[4 * c + 2], wk = d.pend_i[4 * c + 3];
     const int nact_prev = d.nact[c];
     int wbuf = d.wbuf[c];
     int pending = d.pend_i[4 * c + 0], pend_idx = d.pend_i[4 * c + 1];
@@ -508,10 +522,18 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     }
     long long *st = d.stats + (size_t)c * 8;
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, 0);
+    // what an accepted trivial move leaves as logL: the likelihood of the unchanged SS, as the one-at-a-time step computes it
+    auto loglike_of_ss = [&](double s_, double sd_) {
+        double l = R::gaussian_loglike(s_, d.ndata, sd_);
+        if (l != l)
+            l = -1.7976931348623157e308;  // a NaN likelihood is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
+        return l;
+    };
+    const double lstar_prev = loglike_of_ss(ss, sd);
 
     // ---- decisions of the window (prjmh_temper_rf.f90:697-706, :742-751): every group its entry, then the first in order ---
     bool taken = false;
-    int acc_slot = 1 << 30;   // slot of the accepted entry (the window's proposals outside the prior count up to it)
+    int acc_slot = 1 << 30;   // slot of the accepted entry (the window's other slots count up to it)
     int n_eval_upto = 0;      // evaluated entries up to and including the accepted one
     long long d_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -519,34 +541,32 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         const int e = r * NG + g;
         const bool mine = !taken && e < D && e < nwin;      // (group-uniform)
         const int act = e_act[r];
+        const int eslot = e_slot[r] & 0xFFFF;
+        const bool after = (e_slot[r] >> 16) != 0;          // a trivial move was accepted on the path before this entry
         const double part = act == 3 ? ss : e_part[r];      // (3: no source is affected -- the sum IS the current one)
-        // a NaN likelihood (NaN data, an unusable model row) is the reference's -HUGE(1._RP): never accepted (loglhood.f90:197-200)
-        double logl_new = R::gaussian_loglike(part, d.ndata, sd);
-        if (logl_new != logl_new)
-            logl_new = -1.7976931348623157e308;
-        double lr = e_lp[r] + (logl_new - logL) * beta;
+        const double logl_new = loglike_of_ss(part, sd);
+        double lr = e_lp[r] + (logl_new - (after ? lstar_prev : logL)) * beta;
         if (lr > 50.0)
             lr = 50.0;
-        const double u_acc = R::draw_uniform(rng, nsw, e_slot[r], R::DRAW_ACCEPT);
+        const double u_acc = R::draw_uniform(rng, nsw, eslot, R::DRAW_ACCEPT);
         // accept unless u >= exp(logPr + beta (logL' - logL)); a NaN ratio (-HUGE against -HUGE) rejects; an evaluation
         // of the current state (2) is always "taken"
         const bool acc = mine && (act == 2 || (lr == lr && !(u_acc >= exp(lr))));
-        const unsigned long long macc = __ballot(acc) & leads, mmine = __ballot(mine) & leads;
+        const unsigned long long macc = __ballot(acc) & leads;
         const int gfirst = macc ? (__ffsll((long long)macc) - 1) / G : NG;   // the first group (= entry, = slot) that accepts
         // entries decided in this round: the groups up to the accepting one
         const bool decided = mine && g <= gfirst;
         const unsigned long long mdec = __ballot(decided && act != 2) & leads;
-        const unsigned long long mdec_bd = __ballot(decided && act != 2 && e_slot[r] == 0) & leads;
+        const unsigned long long mdec_bd = __ballot(decided && act != 2 && eslot == 0) & leads;
         const unsigned long long mdec_ev = __ballot(decided && (act == 1 || act == 2)) & leads;
         d_st[1] += __popcll(mdec_bd);
         d_st[3] += __popcll(mdec) - __popcll(mdec_bd);
         d_st[6] += __popcll(mdec);   // models that went through the likelihood and were decided
         n_eval_upto += __popcll(mdec_ev);
-        (void)mmine;
         if (macc) {
             // the accepting group's entry becomes the state: its scalars and this lane's node from the lane that holds it
             const int src = gfirst * G;
-            const int a_act = __shfl(act, src, 64), a_pk = __shfl(e_pk[r], src, 64), a_slot = __shfl(e_slot[r], src, 64);
+            const int a_act = __shfl(act, src, 64), a_pk = __shfl(e_pk[r], src, 64), a_slot = __shfl(eslot, src, 64);
             const double a_part = __shfl(part, src, 64), a_logl = __shfl(logl_new, src, 64);
             const double a_pz = __shfl(e_pz[r], src + i, 64), a_pv = __shfl(e_pv[r], src + i, 64);
             ss = a_part;
@@ -571,20 +591,29 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         }
     }
     if (nwin >= 0) {
-        if (!taken)
-            cur = wend;  // the whole window is retired
-        // the window's proposals outside the prior (:707-711), up to the accepted slot: bit j of winv = slot wbase + j
-        {
-            const int wbase = wend - (winv >> 8);  // (winv: invalid-slot bits | slots covered << 8)
-            int nbd = 0, nmh = 0;
-#pragma unroll
-            for (int j = 0; j < PT_SPEC_MAX; ++j)
-                if (((winv >> j) & 1) && wbase + j < acc_slot) {
-                    nbd += wbase + j == 0 ? 1 : 0;
-                    nmh += wbase + j == 0 ? 0 : 1;
+        // the window's slots without a row, up to the accepted slot: proposals outside the prior (:707-711) and trivial moves
+        const int nsl = winv >> 16, wbase = wend - nsl;
+        int upto = acc_slot - wbase;  // window slots that count
+        upto = upto > nsl ? nsl : (upto < 0 ? 0 : upto);
+        const unsigned int mcount = upto >= 32 ? 0xFFFFFFFFu : ((1u << upto) - 1u);
+        const unsigned int binv = (unsigned)winv & 0xFFFFu & mcount, btr = (unsigned)wtr & 0xFFFFu & mcount,
+                           bta = ((unsigned)wtr >> 16) & 0xFFFFu & mcount;
+        const unsigned int bd0 = wbase == 0 ? 1u : 0u;  // window slot 0 is the birth/death slot
+        d_st[1] += __popc((binv | btr) & bd0);
+        d_st[3] += __popc((binv | btr) & ~bd0);
+        d_st[6] += __popc(btr);      // (the one-at-a-time step counts a trivial proposal as a model that was decided)
+        d_st[0] += __popc(bta & bd0);
+        d_st[2] += __popc(bta & ~bd0);
+        if (!taken) {
+            cur = wend;  // the whole window is retired: the state at the end of its path is the chain's
+            if (bta) {
+                k = wk;
+                if (i < k) {
+                    zi = wzi;
+                    vi = wvi;
                 }
-            d_st[1] += nbd;
-            d_st[3] += nmh;
+                logL = lstar_prev;
+            }
         }
         d_st[7] += nact_prev - n_eval_upto > 0 && taken ? nact_prev - n_eval_upto : 0;  // evaluated for nothing
         // The pass that evaluated this window has moved the residuals of an earlier accepted proposal to r2cur (its mover row)
@@ -599,7 +628,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                     d.cache_valid[c] = 1;
             }
         }
-        if (taken && g == 0) {
+        if ((taken || bta) && g == 0) {
             if (lead)
                 d.k[c] = k;
             if (i < k && i < K) {
@@ -616,9 +645,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
             const double sd_new = sd + step * R::draw_normal(rng, nsw, R::SLOT_SIGMA);
             d_st[5] += 1;
             if (sd_new >= p.sdmin && sd_new <= p.sdmax) {
-                double logl_new = R::gaussian_loglike(ss, d.ndata, sd_new);
-                if (logl_new != logl_new)
-                    logl_new = -1.7976931348623157e308;  // as above
+                const double logl_new = loglike_of_ss(ss, sd_new);
                 double lr = (logl_new - logL) * beta;
                 if (lr > 50.0)
                     lr = 50.0;
@@ -649,46 +676,58 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 st[j] += d_st[j];
     }
 
-    // ---- the next window: the slots cur, cur + 1, ... side by side, every proposal drawn from the chain's state -----------
+    // ---- the next window: rounds of the lane groups along the predicted path ------------------------------------------------
     // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the group-dependent branches.
-    const double zi0 = zi, vi0 = vi;
+    double zi0 = zi, vi0 = vi;          // the path's state (starts as the chain's)
+    int kp = k;
+    double lpath = logL;                // ... and its logL
+    const double lstar = loglike_of_ss(ss, sd);
+    const bool propose_on = !eval && !fin;
+    // Rows of this window.  A sweep lasts as long as the chain with the most nodes takes, a pass costs a fixed latency (the step
+    // and the slowest sources of a share) on top of its throughput, and the launch's workgroups are dealt to the chains in
+    // proportion to their slots: with windows in the same proportion every chain needs about the same NUMBER of passes and a
+    // row gets about the same number of workgroups whatever its chain (nspec rows at kmax nodes; profiles/r04y/pt_spec.txt).
+    int Dw = D;
+    if (d.spec_prop && D > 2) {
+        Dw = (D * (2 * k + 1) + 2 * p.kmax) / (2 * p.kmax + 1);
+        Dw = Dw < 2 ? 2 : (Dw > D ? D : Dw);
+    }
+    int nslots = 0, nent = 0;           // slots the window covers, rows it holds
+    unsigned int invbits = 0u, trivbits = 0u, taccbits = 0u;
+    bool any_tacc = false;
+    double my_zq = INFINITY;            // lane e < nent: the shallowest depth entry e changes (its prefix is looked up after the rounds)
     const int up = lane + 1 < 64 ? lane + 1 : 63;
-    const double z_up = __shfl(zi0, up, 64), v_up = __shfl(vi0, up, 64);  // node i + 1 (death shifts the nodes down)
-    const int kc = k < 1 ? 1 : k;
-    const double lpk_k = kc < G ? __shfl(lpk_lo, gbase + (kc & (G - 1)), 64) : __shfl(lpk_hi, gbase + ((kc - G) & (G - 1)), 64);
-    const double lpk_kp = kc + 1 < G ? __shfl(lpk_lo, gbase + ((kc + 1) & (G - 1)), 64)
-                                     : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
-    const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
-                                     : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
     auto group_max = [&](double x) {
 #pragma unroll
         for (int off = G / 2; off > 0; off >>= 1)
             x = fmax(x, __shfl_xor(x, off, 64));
         return x;
     };
-    const double dl_cur = k == 1 ? 9999.9 : group_max((i >= 1 && i < k) ? zi0 : -INFINITY);
-    const double zmin_cur = -group_max(i < k ? -zi0 : -INFINITY);  // the shallowest node: its velocity is the TOP layer's
-    const bool propose_on = !eval && !fin;
-    int nslots = 0;                     // slots the window covers
-    if (propose_on) {
-        nslots = 2 * k - cur;
-        nslots = nslots < 0 ? 0 : (nslots > D ? D : nslots);
-    }
-    int ebase = 0, abase = 0, invbits = 0;
-    int my_e[NR], my_a[NR], my_n0[NR];  // this group's entry of every round, its place among the evaluated ones, its prefix
-    bool my_ev[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int j = r * NG + g;       // this group's slot of the window
-        const int s = cur + j;
-        const bool on = propose_on && j < nslots;
+#pragma unroll 1
+    for (int round = 0; round < PT_WIN_MAX && propose_on; ++round) {
+        int navail = 2 * kp - (cur + nslots);    // slots left in the path's sweep ...
+        navail = navail > NG ? NG : navail;
+        navail = navail > PT_WIN_MAX - nslots ? PT_WIN_MAX - nslots : navail;   // ... and in the window
+        if (navail <= 0 || nent >= Dw)
+            break;
+        const double z_up = __shfl(zi0, up, 64), v_up = __shfl(vi0, up, 64);  // node i + 1 (death shifts the nodes down)
+        const int kc = kp < 1 ? 1 : kp;
+        const double lpk_k = kc < G ? __shfl(lpk_lo, gbase + (kc & (G - 1)), 64) : __shfl(lpk_hi, gbase + ((kc - G) & (G - 1)), 64);
+        const double lpk_kp = kc + 1 < G ? __shfl(lpk_lo, gbase + ((kc + 1) & (G - 1)), 64)
+                                         : __shfl(lpk_hi, gbase + ((kc + 1 - G) & (G - 1)), 64);
+        const double lpk_km = kc - 1 < G ? __shfl(lpk_lo, gbase + ((kc - 1) & (G - 1)), 64)
+                                         : __shfl(lpk_hi, gbase + ((kc - 1 - G) & (G - 1)), 64);
+        const double dl_cur = kp == 1 ? 9999.9 : group_max((i >= 1 && i < kp) ? zi0 : -INFINITY);
+        const double zmin_cur = -group_max(i < kp ? -zi0 : -INFINITY);  // the shallowest node: its velocity is the TOP layer's
+        const int s = cur + nslots + g;  // this group's slot
+        const bool on = g < navail;
         const int propose = s == 0 ? (int)PT_BD : (int)PT_MH;
         const int ivo = s >> 1, ipar = s & 1;
         zi = zi0;
         vi = vi0;
         int moved_node = 0;     // death: the removed node; perturbation: the node; birth: the new node
         double zthr = -INFINITY;
-        int qk = k;
+        int qk = kp;
         double lp = 0.0;
         bool have = false;
         if (on) {
@@ -697,33 +736,33 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 if (p.kmin != p.kmax) {
                     const double u = R::draw_uniform(rng, nsw, 0, R::DRAW_MOVE);
                     int move;
-                    if (k == p.kmax)
+                    if (kp == p.kmax)
                         move = (u <= 0.3333) ? 2 : 0;
-                    else if (k == p.kmin)
+                    else if (kp == p.kmin)
                         move = (u <= 0.3333) ? 1 : 0;
                     else
                         move = (u <= 0.3333) ? 1 : ((u > 0.6666) ? 2 : 0);
                     if (move == 1) {  // BIRTH_FULL (:997-1095): znew = maxpert(1)*u, Vp = minlim(2) + maxpert(2)*u
                         const double zn = (p.hmx - p.hmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_A);
                         const double vn = p.vmin + (p.vmax - p.vmin) * R::draw_uniform(rng, nsw, 0, R::DRAW_B);
-                        if (i == k) {
+                        if (i == kp) {
                             zi = zn;
                             vi = vn;
                         }
-                        qk = k + 1;
+                        qk = kp + 1;
                         lp = lpk_kp - lpk_k;
                         have = true;
-                        moved_node = k;
+                        moved_node = kp;
                         zthr = zn;
-                    } else if (move == 2 && k > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
-                        int idel = 1 + (int)(R::draw_uniform(rng, nsw, 0, R::DRAW_A) * (k - 1));
-                        if (idel > k - 1)
-                            idel = k - 1;
-                        if (i >= idel && i + 1 < k) {
+                    } else if (move == 2 && kp > 1) {  // DEATH_FULL (:917-995): one of nodes 2..k
+                        int idel = 1 + (int)(R::draw_uniform(rng, nsw, 0, R::DRAW_A) * (kp - 1));
+                        if (idel > kp - 1)
+                            idel = kp - 1;
+                        if (i >= idel && i + 1 < kp) {
                             zi = z_up;
                             vi = v_up;
                         }
-                        qk = k - 1;
+                        qk = kp - 1;
                         lp = lpk_km - lpk_k;
                         have = true;
                         moved_node = idel;
@@ -773,28 +812,51 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         // (see pt_step_group: a move that involves the shallowest node changes the model from the surface downwards)
         {
             const int r_moved = __shfl(rk_, gbase + (moved_node & (G - 1)), 64);
-            const bool removed = propose == PT_BD && qk < k;
-            const bool touches_top = have && ((moved_node < k && z_old_moved <= zmin_cur) || (!removed && r_moved == 0));
+            const bool removed = propose == PT_BD && qk < kp;
+            const bool touches_top = have && ((moved_node < kp && z_old_moved <= zmin_cur) || (!removed && r_moved == 0));
             if (touches_top)
                 zthr = -INFINITY;
         }
         const double dl_all = group_max((in && i >= 1) ? zi : -INFINITY);
         const double dl_new = qk == 1 ? 9999.9 : dl_all;
         const bool ok = have && (__ballot(bad) & gmask) == 0ull;
-        const bool trivial = d.incremental && cache_ok && zthr > d.zmax_src && dl_cur > d.zmax_src && dl_new > d.zmax_src;
-        // entries are numbered in slot order: this group's among the groups of the round (one bit per group)
-        const unsigned long long mok = __ballot(ok) & leads, mev = __ballot(ok && !trivial) & leads, minv = __ballot(have && !ok) & leads;
+        const bool trivial = ok && d.incremental && cache_ok && zthr > d.zmax_src && dl_cur > d.zmax_src && dl_new > d.zmax_src;
+        // a trivial move is decided here (prjmh_temper_rf.f90:697-706, :742-751 with an unchanged SS): logL' is the likelihood
+        // of the chain's SS as the one-at-a-time step would compute it after its empty pass
+        bool tacc = false;
+        if (trivial) {
+            double lr = lp + (lstar - lpath) * beta;
+            if (lr > 50.0)
+                lr = 50.0;
+            const double u_acc = R::draw_uniform(rng, nsw, s, R::DRAW_ACCEPT);
+            tacc = lr == lr && !(u_acc >= exp(lr));
+        }
+        const unsigned long long mev = __ballot(ok && !trivial) & leads, mtriv = __ballot(trivial) & leads,
+                                 mtacc = __ballot(tacc) & leads, minv = __ballot(have && !ok) & leads;
+        // the groups that count, a prefix in slot order: up to the first accepted trivial move (the groups behind it drew from
+        // a state the path has left), not beyond the window's rows
+        const int gt = mtacc ? (__ffsll((long long)mtacc) - 1) / G : NG;
+        int ncons = 0, nev = 0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const bool isev = ((mev >> (q * G)) & 1ull) != 0ull;
+            const bool can = q == ncons && q < navail && q <= gt && (!isev || nent + nev < Dw);
+            ncons += can ? 1 : 0;
+            nev += (can && isev) ? 1 : 0;
+        }
+        const bool consumed = g < ncons;
         const unsigned long long below = (1ull << gbase) - 1ull;
-        const int e = ebase + __popcll(mok & below), av = abase + __popcll(mev & below);
-        my_e[r] = e;
-        my_a[r] = av;
-        my_ev[r] = ok && !trivial;
-        my_n0[r] = 0;
+        const int e = nent + __popcll(mev & below);   // this group's row, if it holds an evaluated proposal
+        const bool mine_ev = consumed && ok && !trivial;
 #pragma unroll
         for (int q = 0; q < NG; ++q)
-            if ((minv >> (q * G)) & 1ull)
-                invbits |= 1 << (r * NG + q);
-        if (ok) {
+            if (q < ncons) {
+                const unsigned int bit = 1u << (nslots + q);
+                invbits |= ((minv >> (q * G)) & 1ull) ? bit : 0u;
+                trivbits |= ((mtriv >> (q * G)) & 1ull) ? bit : 0u;
+                taccbits |= ((mtacc >> (q * G)) & 1ull) ? bit : 0u;
+            }
+        if (mine_ev) {
             // LOGLHOOD_RT's call arguments (rtmi_pt_rules.h::pack_model) and the proposal awaiting its decision: row m0 + e
             const int m = m0 + e;
             double *Vr = d.V + (size_t)m * d.ld_model, *Dr = d.D + (size_t)m * d.ld_model;
@@ -817,63 +879,82 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 d.pz[(size_t)m * K + i] = zi;
                 d.pv[(size_t)m * K + i] = vi;
             }
-            if (!trivial && lead)
-                my_n0[r] = prefix_above(d, fmin(zthr, fmin(dl_cur, dl_new)));  // (waited for after the rounds)
             if (lead) {
                 d.pk[m] = qk;
                 d.plp[m] = lp;
-                d.pactive[m] = trivial ? 3 : 1;
-                d.pslot[m] = s;
-                d.NL[m] = trivial ? 0 : nl;  // (trivial: an inactive row -- nothing to evaluate)
-                if (!trivial) {
-                    const int prow = d.nchains + (wbuf * d.nchains + c) * D + e;
-                    rtmi::PtInc *o = d.inc + m;
-                    o->zthr = zthr;
-                    o->dl1 = dl_cur;
-                    o->dl2 = dl_new;
-                    o->pending = pending;
-                    o->pend_idx = pend_idx;
-                    o->mover = av == 0 ? 1 : 0;
-                    o->cur_row = c;
-                    o->prop_row = prow;
-                    rtmi::PtPend *pp = d.pinfo + (size_t)(wbuf * d.nchains + c) * D + e;  // should it be accepted
-                    pp->zthr = zthr;
-                    pp->dl1 = dl_cur;
-                    pp->dl2 = dl_new;
-                    pp->prop_row = prow;
-                    unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;   // the row's sums start from zero
-                    ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
-                    d.alist[m0 + av] = e;
-                }
+                d.pactive[m] = 1;
+                d.pslot[m] = s | (any_tacc ? 1 << 16 : 0);
+                d.NL[m] = nl;
+                const int prow = d.nchains + (wbuf * d.nchains + c) * D + e;
+                rtmi::PtInc *o = d.inc + m;
+                o->zthr = zthr;
+                o->dl1 = dl_cur;
+                o->dl2 = dl_new;
+                o->pending = pending;
+                o->pend_idx = pend_idx;
+                o->mover = e == 0 ? 1 : 0;
+                o->cur_row = c;
+                o->prop_row = prow;
+                rtmi::PtPend *pp = d.pinfo + (size_t)(wbuf * d.nchains + c) * D + e;  // should it be accepted
+                pp->zthr = zthr;
+                pp->dl1 = dl_cur;
+                pp->dl2 = dl_new;
+                pp->prop_row = prow;
+                unsigned long long *ac = d.acc + 4 * (size_t)m * d.part_stride;   // the row's sums start from zero
+                ac[0] = ac[1] = ac[2] = ac[3] = 0ull;
+                d.alist[m] = e;
             }
         }
-        ebase += __popcll(mok);
-        abase += __popcll(mev);
-    }
-    // every evaluated row learns how many workgroups it gets and which prefix of the sorted sources lies above everything its
-    // proposal changes; rows beyond the window are inactive
-    const int nact = abase;
-    if (!eval) {
+        // lane e of the wave keeps what entry e's prefix lookup needs
+        {
+            const double zq = fmin(zthr, fmin(dl_cur, dl_new));
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (lead && my_ev[r]) {
-                const int n0 = my_n0[r];
-                int nw = d.gx_launch;                        // per-slot engine: every row has the batched launch's workgroups
-                if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its evaluated rows
-                    nw = (wg_total - my_a[r] + nact - 1) / nact;
-                    nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
-                }
-                d.rowwg[m0 + my_e[r]] = nw;
-                d.inc[m0 + my_e[r]].n0 = n0;
-                d.pinfo[(size_t)(wbuf * d.nchains + c) * D + my_e[r]].n0 = n0;
+            for (int q = 0; q < NG; ++q) {
+                const double zq_q = __shfl(zq, q * G, 64);
+                const int e_q = nent + __popcll(mev & ((1ull << (q * G)) - 1ull));
+                if (q < ncons && ((mev >> (q * G)) & 1ull) && lane == e_q)
+                    my_zq = zq_q;
             }
-        if (g == 0 && i < D && i >= ebase)
-            d.NL[m0 + i] = 0;
+        }
+        // the path goes on from the state an accepted trivial move leaves (it is the last group that counts)
+        if (gt < ncons) {
+            const double nz = __shfl(zi, gt * G + i, 64), nv = __shfl(vi, gt * G + i, 64);
+            kp = __shfl(qk, gt * G, 64);
+            zi0 = nz;
+            vi0 = nv;
+            lpath = lstar;
+            any_tacc = true;
+        }
+        nent += nev;
+        nslots += ncons;
+    }
+    // every row learns how many workgroups it gets and which prefix of the sorted sources lies above everything its proposal
+    // changes; rows beyond the window are inactive; the end of the path is kept for the decision
+    if (!eval) {
+        if (lane < nent) {
+            const int n0 = prefix_above(d, my_zq);
+            int nw = d.gx_launch;                        // per-slot engine: every row has the batched launch's workgroups
+            if (wg_total > 0) {                          // a chain's own workgroups, dealt round-robin to its rows
+                nw = (wg_total - lane + nent - 1) / nent;
+                nw = nw < 1 ? 1 : nw;                    // (fewer workgroups than rows: they take several rows each)
+            }
+            d.rowwg[m0 + lane] = nw;
+            d.inc[m0 + lane].n0 = n0;
+            d.pinfo[(size_t)(wbuf * d.nchains + c) * D + lane].n0 = n0;
+        }
+        if (lane < D && lane >= nent)
+            d.NL[m0 + lane] = 0;
+        if (any_tacc && g == 0 && i < kp && i < K) {
+            d.wz[row] = zi0;
+            d.wv[row] = vi0;
+        }
         if (lane == 0) {
-            d.nwin[c] = fin ? -1 : ebase;
+            d.nwin[c] = fin ? -1 : nent;
             d.wend[c] = cur + nslots;
-            d.winv[c] = invbits | (nslots << 8);
-            d.nact[c] = nact;
+            d.winv[c] = (int)(invbits | ((unsigned)nslots << 16));
+            d.pend_i[4 * c + 2] = (int)(trivbits | (taccbits << 16));
+            d.pend_i[4 * c + 3] = kp;
+            d.nact[c] = nent;
         }
     } else if (lane == 0) {
         d.nwin[c] = -1;

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rtmi_pt_evaluate": (ctypes.c_int, [_vp]),
     "rtmi_pt_sweep": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rtmi_pt_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "rtmi_pt_chain_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_likelihood_counts": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rtmi_pt_stream_positions": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "rtmi_pt_speculation": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
@@ -449,6 +450,14 @@ class NativeChains:
         _check(self.lib.rtmi_pt_stats(self.h, out))
         names = ("acc_bd", "prop_bd", "acc_mh", "prop_mh", "acc_sd", "prop_sd", "launches", "models")
         return dict(zip(names, [int(x) for x in out]))
+
+
+    def chain_stats(self):
+        """[nchains][8]: the counters of stats() chain by chain (columns acc_bd, prop_bd, acc_mh, prop_mh, acc_sd, prop_sd,
+        models decided, speculated models discarded)."""
+        out = np.zeros((self.n, 8), dtype=np.int64)
+        _check(self.lib.rtmi_pt_chain_stats(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return out
 
 
 def write_rays_dat(path, vels, depths, src_offset, src_depth, p_final) -> None:

@@ -759,7 +759,7 @@ def test_speculative_step_is_exact(kat):
     side in one likelihood pass and decided in order; prjmh_temper_rf.f90:721-759, :669-713, :561-569 run as written, only
     the likelihoods are evaluated ahead of time) must leave every chain -- k, nodes, sigma, logL, SS, temperature, the
     POSITION OF ITS RANDOM STREAM -- every statistic, the ladder and the recorded samples bit-identical to the one-at-a-time
-    step (RTMI_PT_SPECULATE=0), with 1 ... 4 model rows per chain, in both engines.  Shapes: the reference's test_1 data (20
+    step (RTMI_PT_SPECULATE=0), with 1 ... 8 model rows per chain, in both engines.  Shapes: the reference's test_1 data (20
     sources, fused kernel path forced: a source set smaller than one chunk), BASELINE config 4 in miniature (k up to 30,
     birth / death active), and the config-3 shape with interfaces planted exactly on source depths."""
     import raytracerfortran_amd as rt
@@ -795,7 +795,7 @@ def test_speculative_step_is_exact(kat):
             rt.set_sources(sh["off"], sh["dep"], sh["obs"])
             ref, ref_st, info0 = _run_native(sh, {"RTMI_PT_SPECULATE": "0", "RTMI_PT_PERSISTENT": "0"})
             assert info0["rows"] == 1 and ref_st["acc_mh"] > 0
-            for spec, pers in ((1, "0"), (2, "0"), (4, "0"), (3, "1"), (4, "1"), (0, "1")):
+            for spec, pers in ((1, "0"), (2, "0"), (4, "0"), (8, "0"), (3, "1"), (4, "1"), (6, "1"), (8, "1"), (0, "1")):
                 got, st, info = _run_native(sh, {"RTMI_PT_SPECULATE": str(spec), "RTMI_PT_PERSISTENT": pers})
                 assert info["rows"] == max(1, spec), (sh["name"], spec, info)
                 for key in ref:
