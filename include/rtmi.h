@@ -163,11 +163,17 @@ int rtmi_pt_likelihood_counts(const rtmi_pt *h, int64_t *traced, int64_t *cached
 /* position of every chain's counter-based random stream (draws taken so far), ctr[nchains]: part of a chain's state --
  * two runs whose chains AND stream positions agree have taken the same draws for the same decisions */
 int rtmi_pt_stream_positions(rtmi_pt *h, uint64_t *ctr);
-/* The speculative step (RTMI_PT_SPECULATE = model rows per chain, default 4; 0 = one proposal at a time): a perturbation
- * is accepted about one time in five, and the chain's random stream is counter-based, so the proposals of the next slots
- * ASSUMING REJECTION are known in advance; up to that many are evaluated side by side in one likelihood pass and decided in
- * order with the draws the one-at-a-time sampler would take -- the first accepted one becomes the state, the ones behind
- * it are discarded.  Chains, statistics and stream positions are bit-identical to RTMI_PT_SPECULATE=0 (the sums are exact).
+/* The speculative step (RTMI_PT_SPECULATE = model rows per chain, at most 8; 0 = one proposal at a time; default: 6 where a
+ * chain's workgroups hold few sources each and the prior has kmax <= 16, 2 for kmax <= 32, 0 where a pass is bound by
+ * throughput).  The chain's random stream is counter-based, so what it does in the next slots can be laid out ahead of the
+ * likelihoods along a predicted path: a proposal outside the prior is rejected; one that changes the model only below the
+ * deepest source leaves every residual as it is, so its outcome is known when it is drawn; one that changes travel times gets
+ * a model row and is assumed rejected.  The rows of a window are evaluated side by side in one likelihood pass and decided in
+ * order with the draws the one-at-a-time sampler would take -- the first accepted one becomes the state, everything behind it
+ * is discarded.  Chains, statistics and stream positions are bit-identical to RTMI_PT_SPECULATE=0 (the sums are exact).
+ * Where every chain of the ladder is local and sits on a level of its own, rtmi_pt_run puts many sweeps into one launch with
+ * the temperature exchange inside the kernel (a chain meets only its partner of the round; RTMI_PT_MULTI=0: one launch per
+ * sweep) -- same chains, same exchanges.
  * out4: rows per chain (1 = off), models evaluated and then discarded, engine in use (-1 undecided, 0 per-slot launches,
  * 1 persistent launch), 1 if the handle's source set is kept sorted by depth. */
 int rtmi_pt_speculation(rtmi_pt *h, int64_t *out4);

@@ -135,6 +135,26 @@ struct PtSweepArgs {
     unsigned long long *stats;  // NULL, or [8] diagnostic sums (RTMI_PT_QSTATS): ticks in the likelihood, in steps, waiting; passes
     int *walloc;           // speculative form: [2][nchains] weights (slots of the chain's sweep) by which the launch's workgroups
     int parity;            // are dealt to the chains: read from walloc[parity], rewritten for the next sweep in walloc[1 - parity]
+    // ---- launches of SEVERAL sweeps with the temperature exchange inside the kernel (every chain of the ladder local, one chain
+    // per level): a chain that has completed its sweep meets only its PARTNER of the round -- through a mailbox per level --
+    // and goes on, so that a sweep costs what the chains take on average, not what the unluckiest takes (pt_sweep_prop_kernel)
+    int nsweeps;                 // sweeps of this launch; <= 1: one sweep, exchange and sample record by the host's kernels
+    int swap_every, record_every;
+    int s0;                      // index of the launch's first sweep within the host's rtmi_pt_run call (record_every counts from there)
+    long long sweeps_done;       // sweeps the handle had completed before this launch
+    unsigned long long round;    // exchange rounds before this launch
+    unsigned long long seed;     // of the exchange's draws (rtmi_pt_rules.h::swap_pair)
+    int nct;                     // chains of the ladder = levels
+    int *level;                  // [nct]
+    const double *beta_of_level; // [nct]
+    long long *swstats;          // [2] accepted, proposed
+    double *mb_logl;             // [2][nct] mailbox of a level: logL of the chain that sits on it, after its sweep of the round
+    int *mb_chain;               // [2][nct] ... and which chain that is
+    unsigned long long *mb_seq;  // [2][nct] round + 1 once the entry is there (the two halves alternate with the round)
+    int s_cap;                   // sample ring (rtmi_pt_sample_buffer) or 0
+    int *s_count;
+    long long *s_meta;
+    double *s_val;
 };
 
 // Arguments of the single-precision fast forward model (rtmi_f32fast.hip).  Sorted interfaces, positive velocities.

@@ -1381,7 +1381,7 @@ __device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int
 // (The kernel around the likelihood body keeps next to nothing in registers: the body is at its register limit, and whatever
 // lives across it is paid for in spills inside its loops.  The layout, the handshakes and the steps are real calls; what a
 // workgroup has to remember between them -- its chain, its row, the pass -- sits in LDS.)
-enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_WORDS = 8 };
+enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_BEGIN, PROP_SWDONE, PROP_WORDS = 8 };
 
 __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, volatile int *ctl)
 {
@@ -1422,34 +1422,152 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
             ctl[PROP_ROW] = (int)(vb - first);
             ctl[PROP_GX] = (int)(next - first);
             ctl[PROP_BASE] = (int)__hip_atomic_load(wp->count + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl[PROP_BEGIN] = 1;   // the chain's next step is the first of a sweep
+            ctl[PROP_SWDONE] = 0;  // sweeps of this launch the chain has completed
         }
         carry += __shfl(incl, 63, 64);
     }
 }
 
-// The leading workgroup's part of a pass (wave 0 calls): the chain's step(s), the weight of the chain for the next sweep's
-// layout once its sweep is complete, the flag.  Leaves fin | nact in LDS.
+// A chain that has completed a sweep of a multi-sweep launch: the temperature exchange of the round with its PARTNER alone, then
+// the sample record (wave 0 of the chain's leading workgroup calls; lane 0 does the exchange).  The ladder has one chain per level
+// (levels 0 .. nct - 1, every chain local), so a chain's position in the exchange's (level, index) order IS its level, the pair of
+// the round is (a, a + 1) with a = round parity + 2 j, and the decision is rtmi_pt_rules.h::swap_pair's: same draw, same ratio.
+// The two chains find each other through a mailbox per level: logL and chain of the level's occupant, valid once its sequence word
+// says round + 1; both evaluate the same rule on the same numbers and each moves ITSELF.  A chain waits for nobody but its partner,
+// so the chains drift apart by a sweep or so and nobody waits for the unluckiest chain of every sweep (profiles/r04z/chains_4.txt:
+// a chain's sweep takes 535 us on average, the slowest of 32 took 690 us, sweep after sweep).
+__device__ __noinline__ void prop_exchange(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done, int *d_status)
+{
+    namespace R = rtmi_pt_rules;
+    const int lane = threadIdx.x & 63;
+    const long long total = wp->sweeps_done + done;  // sweeps of the handle, this one included
+    int lev = 0;
+    if (wp->swap_every > 0 && total % wp->swap_every == 0) {
+        int newlev = -1;
+        if (lane == 0) {
+            const unsigned long long rnd = wp->round + (unsigned long long)(total / wp->swap_every - wp->sweeps_done / wp->swap_every) - 1ull;
+            const int nct = wp->nct, par = (int)(rnd & 1ull), buf = par;
+            const int L = __hip_atomic_load(wp->level + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int a = ((L - par) & 1) == 0 ? L : L - 1;
+            newlev = L;
+            if (a >= par && a + 1 < nct) {
+                const double mine = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(dp->logL + chain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                wp->mb_logl[(size_t)buf * nct + L] = mine;
+                wp->mb_chain[(size_t)buf * nct + L] = chain;
+                __threadfence();
+                __hip_atomic_store(wp->mb_seq + (size_t)buf * nct + L, rnd + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const int Lp = L == a ? a + 1 : a;
+                unsigned long long *sq = wp->mb_seq + (size_t)buf * nct + Lp;
+                unsigned long long got = 0ull;
+                int polls = 0;
+                bool ok = true;
+#pragma unroll 1
+                for (;;) {
+                    got = __hip_atomic_load(sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (got >= rnd + 1ull)
+                        break;
+                    if (__hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++polls > (1 << 23)) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if (!ok || got != rnd + 1ull) {  // never expected: the partner is gone, or a round ahead of its mailbox's reader
+                    __hip_atomic_store(wp->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d_status)
+                        atomicOr(d_status, 16);
+                } else {
+                    const double theirs = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(wp->mb_logl + (size_t)buf * nct + Lp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const double l1 = L == a ? mine : theirs, l2 = L == a ? theirs : mine;
+                    const double b1 = wp->beta_of_level[a], b2 = wp->beta_of_level[a + 1];
+                    R::Philox p = R::philox_make(wp->seed, 0xFFFFFFFFu, (uint32_t)rnd, ((uint64_t)(rnd >> 32) << 32) | (uint32_t)a);
+                    const double u = R::philox_uniform(p);
+                    double lr = (b2 - b1) * (l1 - l2);
+                    if (lr > 50.0)
+                        lr = 50.0;
+                    const bool acc = b1 != b2 && u <= exp(lr);
+                    if (L == a) {  // the pair is counted once
+                        atomicAdd((unsigned long long *)&wp->swstats[1], 1ull);
+                        if (acc)
+                            atomicAdd((unsigned long long *)&wp->swstats[0], 1ull);
+                    }
+                    if (acc) {
+                        newlev = Lp;
+                        __hip_atomic_store(wp->level + chain, newlev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dp->beta[chain] = wp->beta_of_level[newlev];
+                    }
+                }
+            }
+        }
+        lev = __shfl(newlev, 0, 64);
+    } else {
+        lev = wp->level ? __hip_atomic_load(wp->level + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+    // the chains at T = 1 go to the sample ring: {sweep, chain, k, sd, logL, z[K], v[K]} (as pt_record_kernel, rtmi_pt.hip)
+    if (wp->record_every > 0 && wp->s_cap > 0 && (wp->s0 + done) % wp->record_every == 0 && lev == 0) {
+        int slot = 0;
+        if (lane == 0)
+            slot = atomicAdd(wp->s_count, 1);
+        slot = __shfl(slot, 0, 64);
+        if (slot < wp->s_cap) {
+            const int K = dp->K, k = __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double *o = wp->s_val + (size_t)slot * (2 + 2 * K);
+            if (lane == 0) {
+                wp->s_meta[(size_t)slot * 3 + 0] = total;
+                wp->s_meta[(size_t)slot * 3 + 1] = chain;
+                wp->s_meta[(size_t)slot * 3 + 2] = k;
+                o[0] = dp->sd[chain];
+                o[1] = dp->logL[chain];
+            }
+            for (int j = lane; j < k; j += 64) {
+                o[2 + j] = dp->z[(size_t)chain * K + j];
+                o[2 + K + j] = dp->v[(size_t)chain * K + j];
+            }
+        }
+    }
+}
+
+// The leading workgroup's part of a pass (wave 0 calls): the chain's step(s), the weight of the chain for the next launch's
+// layout once a sweep is complete -- and, in a launch of several sweeps, the exchange and the next sweep's first step right
+// behind it -- then the flag.  Leaves fin | nact in LDS.
 __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, volatile int *ctl, int pass, unsigned int epoch,
-                                       int parity)
+                                       int parity, int *d_status)
 {
     const int chain = ctl[PROP_CHAIN], gx = ctl[PROP_GX];
-    int begin = pass == 0 ? 1 : 0, guard = 0, fin_ = 0, nact_ = 0;
+    const int nsw = wp->nsweeps > 1 ? wp->nsweeps : 1;
+    int guard = 0, fin_ = 0, nact_ = 0;
 #pragma unroll 1
     for (;;) {
-        pt_step_spec_call(dp, chain, begin, gx);
+        pt_step_spec_call(dp, chain, ctl[PROP_BEGIN], gx);
         __threadfence();                  // the rows are out before the flag; and this workgroup (one L1) reads them afresh, too
         __builtin_amdgcn_s_dcache_inv();  // ... and so does a step that follows at once (the chain's words are wave-uniform: scalar loads)
-        begin = 0;
+        ctl[PROP_BEGIN] = 0;
         fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fin_ || nact_ > 0 || ++guard > 4 * RTMI_PT_MAX_K)
+        if (fin_) {
+            const int done = ctl[PROP_SWDONE] + 1;
+            ctl[PROP_SWDONE] = done;
+            if ((threadIdx.x & 63) == 0)  // the weight of this chain in the NEXT launch's layout
+                wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (nsw > 1) {
+                prop_exchange(dp, wp, chain, done, d_status);
+                __threadfence();
+                __builtin_amdgcn_s_dcache_inv();
+                if (done < nsw && __hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    ctl[PROP_BEGIN] = 1;  // the next sweep at once
+                    guard = 0;
+                    continue;
+                }
+            }
+            break;
+        }
+        if (nact_ > 0 || ++guard > 4 * RTMI_PT_MAX_K)
             break;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (fin_)  // the weight of this chain in the NEXT sweep's layout
-            wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if ((threadIdx.x & 63) == 0)
         __hip_atomic_store(wp->flag + chain, epoch + (unsigned int)pass + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // After the flag: what the chain does in this pass (thread 0 of every workgroup of the chain).  ctl[PROP_NACT] = rows to
@@ -1504,7 +1622,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
             dg[6] = __builtin_amdgcn_s_memrealtime();
         if (ctl[PROP_ROW] == 0) {
             if (threadIdx.x < 64)
-                prop_lead(dp, wp, ctl, pass, epoch, parity);
+                prop_lead(dp, wp, ctl, pass, epoch, parity, a.d_status);
             if (diag && threadIdx.x == 0) {
                 dg[1] += __builtin_amdgcn_s_memrealtime() - dg[6];
                 dg[4] += 1ull;
@@ -1535,7 +1653,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
                 if (ctl[PROP_ROW] == 0) {  // per chain (its leading workgroup): ticks, sweeps, the longest, passes
                     unsigned long long *q = st + 8 + 4 * (size_t)ctl[PROP_CHAIN];
                     q[0] += life;
-                    q[1] += 1ull;
+                    q[1] += (unsigned long long)(wp->nsweeps > 1 ? wp->nsweeps : 1);
                     q[2] = life > q[2] ? life : q[2];
                     q[3] += dg[3];
                 }

@@ -257,7 +257,12 @@ struct rtmi_pt {
     unsigned long long *d_qstats = nullptr;  // RTMI_PT_QSTATS: where the workgroups' time went (printed by rtmi_pt_run)
     int *d_walloc = nullptr;         // [2][nchains] (rtmi_pt_dev.hpp::PtDev::walloc)
     int sweep_parity = 0;
-    rtmi::PtSweepArgs *d_wprop = nullptr;  // device copy of the proportional engine's constant words
+    rtmi::PtSweepArgs *d_wprop = nullptr;  // device copy of the proportional engine's words ...
+    rtmi::PtSweepArgs wprop;               // ... and the host's (the words of a multi-sweep launch are rewritten before it)
+    bool levels_perm = false;              // the ladder has one chain per level, levels 0 .. nct - 1 (set_ladder): a chain's level IS its position
+    double *d_mb_logl = nullptr;           // [2][nct] | the exchange's mailboxes (multi-sweep launches, rtmi_kernels.hip::prop_exchange)
+    int *d_mb_chain = nullptr;             // [2][nct] |
+    unsigned long long *d_mb_seq = nullptr;  // [2][nct] |
     std::vector<rtmi::PtInc> inc0;   // (one-at-a-time step) the rows of the residual slab never change: a chain's record as reset by rtmi_pt_set_chain
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -362,6 +367,54 @@ int enqueue_sweep(rtmi_pt *h, int nslots_k)
     return RTMI_OK;
 }
 
+// S sweeps in ONE launch of the proportional engine, the temperature exchange and the sample record inside the kernel
+// (rtmi_kernels.hip::prop_exchange): every chain of the ladder is local and sits on a level of its own.  Returns -1 when the
+// launch is refused (the caller goes on with single sweeps).
+int sweep_multi(rtmi_pt *h, int S, int swap_every, int record_every, int s0)
+{
+    const int kmax = h->d.pr.kmax;
+    rtmi::PtSweepArgs &w = h->wprop;
+    w.nsweeps = S;
+    w.swap_every = swap_every;
+    w.record_every = record_every;
+    w.s0 = s0;
+    w.sweeps_done = h->sweeps_done;
+    w.round = h->round;
+    w.seed = h->d.seed;
+    w.nct = h->nct;
+    w.level = h->d_level;
+    w.beta_of_level = h->d_beta_of_level;
+    w.swstats = h->d_swstats;
+    w.mb_logl = h->d_mb_logl;
+    w.mb_chain = h->d_mb_chain;
+    w.mb_seq = h->d_mb_seq;
+    w.s_cap = h->d_s_count ? h->s_cap : 0;
+    w.s_count = h->d_s_count;
+    w.s_meta = h->d_s_meta;
+    w.s_val = h->d_s_val;
+    HIP_TRY(hipMemcpyAsync(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice, h->stream));
+    const int nslots = S * (kmax + 1);  // (the kernel's bound of the passes: 2 x this + 2)
+    const size_t n = (size_t)h->nsrc;
+    if (launch_pt_prop(h->d.V, h->d.D, h->d.NL, h->ld_model, h->nchains, h->max_nl, h->d_set, h->d_set + n, h->nsrc, h->d_set + 2 * n,
+                       h->cus, h->d_ptdev, sizeof h->d, h->d_wprop, h->nspec, h->epoch, h->sweep_parity, nslots, h->stream,
+                       h->incremental ? h->d.inc : nullptr, h->d_r2, h->d_inc_counts, h->d_partial_x, h->d.part_stride,
+                       h->d_pinfo, h->nrows * h->d.part_stride) != RTMI_OK) {
+        w.nsweeps = 1;
+        HIP_TRY(hipMemcpyAsync(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice, h->stream));
+        return -1;
+    }
+    const unsigned int span = (unsigned int)(2 * nslots + 4);
+    h->epoch += span > 4096u ? span : 4096u;
+    h->sweep_parity ^= 1;
+    h->launches += 1;
+    const long long before = h->sweeps_done;
+    h->sweeps_done += S;
+    if (swap_every > 0)
+        h->round += (uint64_t)(h->sweeps_done / swap_every - before / swap_every);
+    h->kbound = h->kbound + S < kmax ? h->kbound + S : kmax;
+    return RTMI_OK;
+}
+
 // engine: 0 per-slot launches, 1 the persistent launch (falls back if refused).  ev0 / ev1 (may be NULL) are recorded on the
 // stream right around the sweep's launches.
 int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *slots_out = nullptr)
@@ -385,6 +438,10 @@ int sweep_once(rtmi_pt *h, int engine, hipEvent_t ev0 = nullptr, hipEvent_t ev1 
     };
     if (engine == 1 && h->use_persistent && h->spec && h->nchains <= h->cus && h->d_ptdev && h->d_partial_x) {
         // the speculative sweep, workgroups dealt to the chains in proportion to their slots: one cooperative launch
+        if (h->wprop.nsweeps > 1) {  // (a multi-sweep launch went before: this one is a single sweep, the exchange is the host's)
+            h->wprop.nsweeps = 1;
+            HIP_TRY(hipMemcpyAsync(h->d_wprop, &h->wprop, sizeof h->wprop, hipMemcpyHostToDevice, h->stream));
+        }
         if (ev0)
             HIP_TRY(hipEventRecord(ev0, h->stream));
         Closer closer{ev1, h->stream};
@@ -550,13 +607,14 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     // a chain is bit for bit the chain of the one-at-a-time step.  RTMI_PT_SPECULATE = rows per chain (0: the one-at-a-time
     // step pt_step_group).
     // Default: speculate where a pass is bound by the LATENCY of a likelihood evaluation -- a chain's workgroups hold a
-    // couple of records per lane or fewer (BASELINE config 3: 1e4 sources over 8 workgroups; 0.92 -> 0.74 ms per sweep,
-    // profiles/r04c/pt_timings.txt, r04s/pt_teams.txt) -- and not where it is bound by throughput (config 4's share, 1e5 sources
-    // per chain: every speculated model that is thrown away is work the machine had no room for, 3.07 -> 3.97 ms).  Rows per
-    // chain = what one round of the step's lane groups takes (K <= 16: four groups -- four rows, on two workgroups of 512 lanes
-    // per CU, rtmi_launch_pt_prop; with one workgroup of 1024 per CU three rows measured best; K <= 32: two).
+    // couple of records per lane or fewer (BASELINE config 3: 1e4 sources over 8 workgroups; one proposal at a time 0.92 ms per
+    // sweep, six rows along the predicted path in multi-sweep launches 0.59: profiles/r04ab/pt_scan.txt) -- and not where it is
+    // bound by throughput (config 4's share, 1e5 sources per chain: every speculated model that is thrown away is work the
+    // machine had no room for, and the window's step costs more than the one-at-a-time step: 3.10 -> 3.7 ... 3.9 ms).  Rows
+    // per chain: K <= 16: six (four groups of the step's wave work side by side, a window is two rounds of them or more; on two
+    // workgroups of 512 lanes per CU, rtmi_launch_pt_prop); K <= 32: two.
     const int gx0 = batch_grid_x(nchains, h->max_nl, c.set_n, c.cus);
-    int want_spec = (c.set_n / (gx0 > 0 ? gx0 : 1) <= RTMI_PT_SPECULATE_MAX_SHARE) ? (prior->kmax <= 16 ? 4 : 2) : 0;
+    int want_spec = (c.set_n / (gx0 > 0 ? gx0 : 1) <= RTMI_PT_SPECULATE_MAX_SHARE) ? (prior->kmax <= 16 ? 6 : 2) : 0;
     if (const char *e = getenv("RTMI_PT_SPECULATE"))
         want_spec = atoi(e);
     if (want_spec > PT_SPEC_MAX)
@@ -627,6 +685,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         w.walloc = h->d_walloc;
         w.stats = h->d_qstats;
         w.xcd_map = getenv("RTMI_PT_POISON_LDS") ? 77 : 0;  // (diagnostic: pt_sweep_prop_kernel fills its LDS with NaN patterns first)
+        w.nsweeps = 1;
+        h->wprop = w;
         ok = hipMalloc((void **)&h->d_wprop, sizeof w) == hipSuccess && hipMemcpy(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok)
@@ -816,7 +876,7 @@ void rtmi_pt_destroy(rtmi_pt *h)
         (void)hipGraphExecDestroy(g.second);
     void *bufs[] = {h->d_set, h->d_f64, h->d_i32, h->d_u64, h->d_partial, h->d_logpk, h->d_level, h->d_order,
                     h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_s_count, h->d_s_meta, h->d_s_val, h->d_sync, h->d_ptdev, h->d_inc, h->d_cache_valid, h->d_r2, h->d_inc_counts, h->d_partial_x,
-                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qstats, h->d_walloc, h->d_wprop};
+                    h->d_cdf, h->d_spec_i32, h->d_spec_u64, h->d_pend_z, h->d_pinfo, h->d_qstats, h->d_walloc, h->d_wprop, h->d_mb_logl, h->d_mb_chain, h->d_mb_seq};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -963,10 +1023,13 @@ int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    void *old[] = {h->d_level, h->d_order, h->d_logl_all, h->d_beta_of_level, h->d_swstats};
+    void *old[] = {h->d_level, h->d_order, h->d_logl_all, h->d_beta_of_level, h->d_swstats, h->d_mb_logl, h->d_mb_chain, h->d_mb_seq};
     for (void *b : old)
         if (b)
             HIP_TRY(hipFree(b));
+    h->d_mb_logl = nullptr;
+    h->d_mb_chain = nullptr;
+    h->d_mb_seq = nullptr;
     h->d_level = h->d_order = nullptr;
     h->d_logl_all = h->d_beta_of_level = nullptr;
     h->d_swstats = nullptr;
@@ -983,6 +1046,23 @@ int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int
     h->first = first_chain;
     h->nlevels = nlevels;
     h->round = 0;
+    {
+        // one chain per level, levels 0 .. nct - 1: the exchange can then run inside a multi-sweep launch (a chain's level is its
+        // position in the exchange's order, and stays a permutation under exchanges)
+        std::vector<char> seen(nct, 0);
+        bool perm = nlevels == nchains_total;
+        for (size_t i = 0; perm && i < nct; ++i) {
+            perm = !seen[(size_t)level[i]];
+            seen[(size_t)level[i]] = 1;
+        }
+        h->levels_perm = perm;
+        HIP_TRY(hipMalloc((void **)&h->d_mb_logl, 2 * nct * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&h->d_mb_chain, 2 * nct * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&h->d_mb_seq, 2 * nct * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(h->d_mb_logl, 0, 2 * nct * sizeof(double)));
+        HIP_TRY(hipMemset(h->d_mb_chain, 0, 2 * nct * sizeof(int)));
+        HIP_TRY(hipMemset(h->d_mb_seq, 0, 2 * nct * sizeof(unsigned long long)));
+    }
     std::vector<double> b((size_t)h->nchains);
     for (int c = 0; c < h->nchains; ++c)
         b[(size_t)c] = beta_of_level[level[first_chain + c]];
@@ -1122,21 +1202,31 @@ int rtmi_pt_samples(rtmi_pt *h, int max_samples, int64_t *sweep, int *chain, int
             hipMemcpy(val.data(), h->d_s_val, val.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
             return -RTMI_ERR_HIP;
     }
-    for (int i = 0; i < n; ++i) {
+    // in the order (sweep, chain): the ring is filled in the order the chains get there (within a multi-sweep launch the chains
+    // are not in step), the caller sees one order whatever the engine
+    std::vector<int> ord((size_t)n);
+    for (int i = 0; i < n; ++i)
+        ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&meta](int a, int b) {
+        const long long sa = meta[(size_t)a * 3], sb = meta[(size_t)b * 3];
+        return sa != sb ? sa < sb : meta[(size_t)a * 3 + 1] < meta[(size_t)b * 3 + 1];
+    });
+    for (int o = 0; o < n; ++o) {
+        const int i = ord[(size_t)o];
         if (sweep)
-            sweep[i] = meta[(size_t)i * 3];
+            sweep[o] = meta[(size_t)i * 3];
         if (chain)
-            chain[i] = (int)meta[(size_t)i * 3 + 1];
+            chain[o] = (int)meta[(size_t)i * 3 + 1];
         if (k)
-            k[i] = (int)meta[(size_t)i * 3 + 2];
+            k[o] = (int)meta[(size_t)i * 3 + 2];
         if (sd)
-            sd[i] = val[(size_t)i * w];
+            sd[o] = val[(size_t)i * w];
         if (logL)
-            logL[i] = val[(size_t)i * w + 1];
+            logL[o] = val[(size_t)i * w + 1];
         if (depths)
-            memcpy(depths + (size_t)i * K, &val[(size_t)i * w + 2], K * sizeof(double));
+            memcpy(depths + (size_t)o * K, &val[(size_t)i * w + 2], K * sizeof(double));
         if (vels)
-            memcpy(vels + (size_t)i * K, &val[(size_t)i * w + 2 + K], K * sizeof(double));
+            memcpy(vels + (size_t)o * K, &val[(size_t)i * w + 2 + K], K * sizeof(double));
     }
     if (hipMemset(h->d_s_count, 0, sizeof(int)) != hipSuccess)
         return -RTMI_ERR_HIP;
@@ -1176,8 +1266,28 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
                     (void)hipEventDestroy(e[i]);
         }
     } ev_guard{ev};
+    // Several sweeps per launch, the exchange inside the kernel: where every chain of the ladder is local and has a level of its
+    // own (RTMI_PT_MULTI=0 keeps one launch per sweep; a ladder with several chains on a level, chains on other ranks, or no
+    // ladder: one launch per sweep, the exchange between the launches)
+    const bool multi_env = !(getenv("RTMI_PT_MULTI") && !strcmp(getenv("RTMI_PT_MULTI"), "0"));
+    bool multi_ok = multi_env && h->use_persistent && h->spec && h->nchains <= h->cus && h->d_ptdev && h->d_partial_x &&
+                    (!comm || rtmi_comm_size(comm) == 1) && h->d_level && h->levels_perm && h->nct == h->nchains && h->first == 0 &&
+                    h->nct >= 2 && h->d_mb_seq;
     for (int s = 0; s < nsweeps; ++s) {
         int rc;
+        if (multi_ok && h->engine == 1 && nsweeps - s >= 2) {  // (a single sweep: one launch, the exchange by the host's kernel)
+            int S = nsweeps - s;
+            const int smax = 2000 / (h->d.pr.kmax + 2) > 1 ? 2000 / (h->d.pr.kmax + 2) : 1;
+            S = S > smax ? smax : S;
+            const int rcm = sweep_multi(h, S, swap_every, record_every, s);
+            if (rcm == RTMI_OK) {
+                s += S - 1;
+                continue;
+            }
+            if (rcm > 0)
+                return rcm;
+            multi_ok = false;  // refused: single sweeps from here on
+        }
         if (trial && t0 < 0 && h->engine < 0 && nsweeps - s >= 10) {
             // not before the sweeps have the length they keep: the bound of k that sizes a sweep grows by one per sweep
             // up to kmax (it is only refreshed at a synchronisation), and a sweep of kmax node slots, many of them

@@ -807,6 +807,88 @@ def test_speculative_step_is_exact(kat):
             rt.set_option("path", 0)
 
 
+def _run_native_ladder(shape, env, level, betas, calls):
+    """As _run_native with a ladder of one chain per level and several rtmi_pt_run calls (sweeps, swap_every, record_every)."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h = raymod.NativeChains(shape["nch"], shape["ld"], shape["off"].size, shape["prior"], seed=shape["seed"])
+        for i in range(shape["nch"]):
+            h.set_chain(i, shape["nodes"][i % len(shape["nodes"])], shape["sd"], 1.0)
+        h.evaluate()
+        h.set_ladder(shape["nch"], 0, level, betas)
+        h.sample_buffer(8192)
+        for nsw, swap_every, rec in calls:
+            h.run(nsw, swap_every, None, rec)
+        a = h.get_all()
+        live = np.arange(a["z"].shape[1])[None, :] < a["k"][:, None]
+        st = {k: v for k, v in h.stats().items() if k != "launches"}
+        launches = h.stats()["launches"]
+        smp = h.samples()
+        lev, acc, prop = h.get_ladder()
+        out = {"k": a["k"], "z": np.where(live, a["z"], 0.0), "v": np.where(live, a["v"], 0.0), "sd": a["sd"], "logL": a["logL"],
+               "ss": a["ss"], "beta": a["beta"], "ctr": h.stream_positions(), "level": lev, "swaps": np.array([acc, prop]),
+               "smp_sweep": smp["sweep"], "smp_chain": smp["chain"], "smp_k": smp["k"], "smp_logL": smp["logL"], "smp_sd": smp["sd"]}
+        del h
+        assert rt.load_library().rtmi_device_status() == 0
+        return out, st, launches
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_multi_sweep_launch_with_the_exchange_inside_the_kernel_is_exact():
+    """Where every chain of the ladder is local and sits on a level of its own, rtmi_pt_run puts MANY sweeps into one launch of
+    the sweep kernel and the temperature exchange (TEMPSWP_MH, prjmh_temper_rf.f90:1329-1357) inside it: a chain that has
+    completed its sweep meets only its partner of the round -- through a mailbox per level -- and goes on, so nobody waits for the
+    unluckiest chain of every sweep (csrc/rtmi_kernels.hip::prop_exchange).  Chains, stream positions, levels, exchange
+    counters, statistics and the recorded samples must be those of one launch per slot with the exchange kernel between the
+    sweeps (RTMI_PT_SPECULATE=0, RTMI_PT_PERSISTENT=0) -- over several rtmi_pt_run calls, with exchanges after every sweep and
+    after every other, samples every third and fifth sweep, on config 3's shape and on config 4 in miniature (k up to 30)."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import synthetic as S
+    from oracle import oracle as O
+    rt.load_library(); rt.init(0)
+    shapes = []
+    n = 6000
+    off, dep = S.sampler_sources(n, 6)
+    obs = rt.dff(S.TRUE_V, S.TRUE_D, len(S.TRUE_D), off, dep, n)["timeP"] + np.random.default_rng(3).normal(0, 0.016, n)
+    base = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])
+    shapes.append({"name": "config-3 shape", "off": off, "dep": dep, "obs": obs, "nch": 32, "ld": 11, "prior": T.Prior(),
+                   "seed": 21, "nodes": [base], "sd": 0.016, "dT": 1.15})
+    off, dep = S.sampler_sources(3000, 77)
+    rng = np.random.default_rng(78)
+    z = np.concatenate([[0.0], np.sort(rng.uniform(300.0, 9000.0, 11))])
+    z[1:] += np.arange(11) * 150.0
+    nodes12 = np.column_stack([z, rng.uniform(2000.0, 8000.0, 12)])
+    vv, dd = T.layering(nodes12)
+    obs = O.oracle_dff(vv, dd, off, dep) + rng.normal(0.0, 0.02, off.size)
+    shapes.append({"name": "config-4 miniature", "off": off, "dep": dep, "obs": obs, "nch": 16, "ld": 31,
+                   "prior": T.Prior(kmin=2, kmax=30, lam=10.0), "seed": 9, "nodes": [nodes12], "sd": 0.02, "dT": 1.2})
+    calls = [(25, 1, 3), (1, 1, 1), (14, 2, 5), (7, 0, 2)]
+    for sh in shapes:
+        rt.set_sources(sh["off"], sh["dep"], sh["obs"])
+        nch = sh["nch"]
+        level = np.random.default_rng(5).permutation(nch)           # one chain per level, in no particular order
+        betas = sh["dT"] ** -np.arange(float(nch))
+        ref, ref_st, _ = _run_native_ladder(sh, {"RTMI_PT_SPECULATE": "0", "RTMI_PT_PERSISTENT": "0"}, level, betas, calls)
+        assert ref["swaps"][0] > 0 and ref["smp_k"].size > 0
+        for env in ({"RTMI_PT_SPECULATE": "4", "RTMI_PT_PERSISTENT": "1"}, {"RTMI_PT_SPECULATE": "8", "RTMI_PT_PERSISTENT": "1"},
+                    {"RTMI_PT_SPECULATE": "4", "RTMI_PT_PERSISTENT": "1", "RTMI_PT_MULTI": "0"}):
+            got, st, launches = _run_native_ladder(sh, env, level, betas, calls)
+            for key in ref:
+                assert np.array_equal(ref[key], got[key]), (sh["name"], env, key)
+            assert st == ref_st, (sh["name"], env, st, ref_st)
+            if env.get("RTMI_PT_MULTI") != "0":
+                assert launches <= 2 * len(calls) + 2, (sh["name"], env, launches)   # many sweeps per launch (+ the evaluation's)
+
+
 @pytest.mark.gpu
 def test_device_sampler_keeps_a_sentinel_residual_finite(golden_batches):
     """A source the reference gives up on (-999, subroutineR-quiet.f90:167-169) enters SUM(DresRT**2) as (t_obs + 999)^2 -- about
