@@ -672,8 +672,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         ok = hipMemcpy(h->d_walloc, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok && h->spec && getenv("RTMI_PT_QSTATS"))  // diagnostic: where the workgroups' time goes (printed by rtmi_pt_run)
-        ok = hipMalloc((void **)&h->d_qstats, (8 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess &&   // + per chain: ticks, sweeps, longest, passes
-             hipMemset(h->d_qstats, 0, (8 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess;
+        ok = hipMalloc((void **)&h->d_qstats, (16 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess &&   // + per chain: ticks, sweeps, longest, passes; + 8 phase clocks of the step
+             hipMemset(h->d_qstats, 0, (16 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         rtmi::PtSweepArgs w;
         memset(&w, 0, sizeof w);
@@ -784,6 +784,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.ncdf = ncdf;
     d.nspec = h->nspec;
     d.spec_step = h->spec ? 1 : 0;
+    d.dbg = (h->d_qstats && getenv("RTMI_PT_QSTATS") && atoi(getenv("RTMI_PT_QSTATS")) >= 3) ? h->d_qstats + 8 + 4 * nc : nullptr;
     d.spec_prop = (getenv("RTMI_PT_SPEC_PROP") ? atoi(getenv("RTMI_PT_SPEC_PROP")) : 0) ? 1 : 0;
     d.part_stride = pstride;
     d.gx_launch = h->gx_launch;
@@ -1334,10 +1335,17 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     }
     const int rc = finish(h);  // the one synchronisation of the call
     if (!rc && h->d_qstats) {
-        std::vector<unsigned long long> stv(8 + 4 * (size_t)h->nchains);
+        std::vector<unsigned long long> stv(16 + 4 * (size_t)h->nchains);
         unsigned long long *st = stv.data();
         HIP_TRY(hipMemcpy(st, h->d_qstats, stv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(h->d_qstats, 0, stv.size() * sizeof(unsigned long long)));
+        if (h->d.dbg) {
+            const unsigned long long *q = st + 8 + 4 * (size_t)h->nchains;
+            const double n = q[6] ? (double)q[6] : 1.0;
+            fprintf(stderr, "rtmi:   the step, per call (%llu calls, %.2f slots per window): loads %.1f us, decisions %.1f, sigma + state %.1f, the window's rounds %.1f, "
+                            "prefix + words + stores out %.1f; whole call %.1f us\n", q[6], (double)q[7] / n, 0.01 * q[0] / n, 0.01 * q[1] / n, 0.01 * q[2] / n,
+                    0.01 * q[3] / n, 0.01 * q[4] / n, 0.01 * q[5] / n);
+        }
         if (st[5] > 0 && getenv("RTMI_PT_QSTATS") && atoi(getenv("RTMI_PT_QSTATS")) >= 2) {
             // how long the chains' sweeps take (their leading workgroups, kernel entry to the end of the chain's sweep)
             std::vector<double> beta(h->nchains);

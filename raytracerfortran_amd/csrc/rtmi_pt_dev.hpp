@@ -55,6 +55,7 @@ struct PtDev {
     int nspec;
     int spec_step;        // the handle runs pt_step_spec (RTMI_PT_SPECULATE >= 1); 0 = the one-at-a-time step pt_step_group
     int spec_prop;        // 1: a window holds rows in proportion to the chain's slots (nspec at kmax nodes), see pt_step_spec
+    unsigned long long *dbg;  // NULL, or [8] diagnostic (RTMI_PT_QSTATS=3): 100 MHz ticks of pt_step_spec's phases, summed over the calls
     int part_stride;      // residual sums of row m: partial_x[(m * part_stride + j) * 4], j < rowwg[m]
     int *cur;             // [nchains] the chain's next undecided slot of the current sweep (0 = birth/death, s = (node s>>1, parameter s&1))
     int *fin;             // [nchains] the sweep's sigma move is done: nothing left to do until the next sweep
@@ -521,6 +522,15 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         e_part[r] = rtmi::acc_to_double(tot);
     }
     long long *st = d.stats + (size_t)c * 8;
+    unsigned long long tk0 = 0ull, tk1 = 0ull;
+    if (d.dbg) {
+        tk0 = __builtin_amdgcn_s_memrealtime();
+        if (e_part[0] + zi + wzi + sd + lpk_lo == 1.2345e301)  // (waits for the loads)
+            tk0 += 1ull;
+        tk1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0)
+            atomicAdd(d.dbg + 0, tk1 - tk0);   // phase 0: the loads' round trip (from the first use)
+    }
     R::Philox rng = R::philox_make(d.seed, d.stream_id, (uint32_t)c, 0);
     // what an accepted trivial move leaves as logL: the likelihood of the unchanged SS, as the one-at-a-time step computes it
     auto loglike_of_ss = [&](double s_, double sd_) {
@@ -638,6 +648,12 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         }
     }
 
+    if (d.dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && (cur + k) != -12345)
+            atomicAdd(d.dbg + 1, t - tk1);   // phase 1: the decisions
+        tk1 = t;
+    }
     // ---- sigma (EXPLORE_MH :521-575, PROPOSAL_SDRT :1616-1630) once every slot of the sweep is decided ------------------
     if (!eval && !fin && cur >= 2 * k) {
         if (R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_MOVE) >= 0.10) {
@@ -676,6 +692,12 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 st[j] += d_st[j];
     }
 
+    if (d.dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0)
+            atomicAdd(d.dbg + 2, t - tk1);   // phase 2: sigma, the chain's words written
+        tk1 = t;
+    }
     // ---- the next window: rounds of the lane groups along the predicted path ------------------------------------------------
     // Cross-lane steps (shuffles, ballots) are taken by every lane of the wave, outside the group-dependent branches.
     double zi0 = zi, vi0 = vi;          // the path's state (starts as the chain's)
@@ -928,6 +950,15 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         nent += nev;
         nslots += ncons;
     }
+    if (d.dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && nent + nslots != -12345) {
+            atomicAdd(d.dbg + 3, t - tk1);   // phase 3: the window's rounds
+            atomicAdd(d.dbg + 6, 1ull);      // calls
+            atomicAdd(d.dbg + 7, (unsigned long long)nslots);
+        }
+        tk1 = t;
+    }
     // every row learns how many workgroups it gets and which prefix of the sorted sources lies above everything its proposal
     // changes; rows beyond the window are inactive; the end of the path is kept for the decision
     if (!eval) {
@@ -960,6 +991,14 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         d.nwin[c] = -1;
         d.nact[c] = 0;
         d.walloc[c] = d.walloc[d.nchains + c] = 2 * k + 1;
+    }
+    if (d.dbg) {
+        __threadfence();
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            atomicAdd(d.dbg + 4, t - tk1);   // phase 4: prefix lookups, the window's words, until the stores are out
+            atomicAdd(d.dbg + 5, t - tk0);   // the whole call
+        }
     }
 }
 
