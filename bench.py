@@ -515,10 +515,12 @@ def run_pt(rt, torch, dist, rank, world, dev, nsrc, kmax, steps, warmup):
         tot = tm.cpu().numpy()
     launches = st1["launches"] - st0["launches"]
     eng = sp1["engine"]   # what the handle runs: 1 persistent, 0 per-slot launches, -1 still undecided (no long call yet)
-    engine = ("one persistent cooperative launch per sweep" if eng == 1 else
+    multi = eng == 1 and launches * 4 < max(1, steps)   # the library put many sweeps into one launch (every chain local, one chain per level)
+    engine = ("persistent cooperative launches of many sweeps each, the temperature exchange inside the kernel (chain meets partner)" if multi else
+              "one persistent cooperative launch per sweep" if eng == 1 else
               ("two launches per proposal slot / pass, replayed as a hipGraph" if eng == 0 or launches > 2 * max(1, steps)
                else "undecided (per-slot launches so far)"))
-    exchange = ("RCCL all-gather of 8 B per chain (rtmi_pt_swap_round)" if s.comm is not None
+    exchange = ("RCCL all-gather of 8 B per chain (rtmi_pt_swap_round)" if (s.comm is not None and world > 1)
                 else ("every chain local: no collective" if world == 1 else "host gather (gloo rehearsal)"))
     return {"elapsed": elapsed, "models": float(tot[0]), "traced": float(tot[1]), "cached": float(tot[2]), "discarded": float(tot[3]),
             "launches": launches, "engine": engine, "engine_trial_sweeps": settle if device_loop else 0, "exchange": exchange, "level": s.level, "nloc": nloc, "speculation_rows": sp1["rows"],

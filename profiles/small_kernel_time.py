@@ -8,8 +8,9 @@ import torch
 import raytracerfortran_amd as rt
 from raytracerfortran_amd.synthetic import c2_workload
 rt.load_library(); rt.init(0)
-v, d, off, dep = c2_workload(16384)
-for n in (1, 20, 64, 256, 4096, 10000):
+v, d, off, dep = c2_workload(131072)
+sizes = [int(x) for x in sys.argv[1:]] or [1, 20, 64, 256, 4096, 10000]
+for n in sizes:
     a = [torch.tensor(x, device="cuda") for x in (v, d, off[:n], dep[:n])]
     for _ in range(20):
         rt.trace_device(*a)

@@ -921,7 +921,8 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
     rc = status_word_for((hipStream_t)stream, &d_status);
     if (rc)
         return rc;
-    const bool fused = tn.force_path != 1 && (nsrc >= RTMI_FUSED_MIN_NSRC || tn.force_path == 2);
+    // (launches the group-of-lanes kernel takes go to it unless a path is forced: rtmi_kernels.h::rtmi_small_kernel_takes)
+    const bool fused = tn.force_path != 1 && (tn.force_path == 2 || (nsrc >= RTMI_FUSED_MIN_NSRC && (tn.d_stamps || !rtmi_small_kernel_takes(nsrc, nlayers))));
     if (fused) {
         rtmi::FusedArgs fa;
         memset(&fa, 0, sizeof fa);
@@ -956,6 +957,7 @@ int rtmi_trace_device(const double *d_vels, const double *d_depths, int nlayers,
     a.nsrc = nsrc;
     a.d_timeP = d_timeP;
     a.d_p_final = d_p_final;
+    a.lane_per_source = tn.force_path == 1 ? 1 : 0;
     const int gx = rtmi_launch_grid_x(nsrc, 1, num_cus_for_current_device());
     HIP_TRY(rtmi_launch_trace(&a, 1, nlayers, gx, (hipStream_t)stream));
     return RTMI_OK;

@@ -12,6 +12,26 @@
 #define RTMI_POOL 256         // slots of the hand-over ring (power of two)
 #define RTMI_PROMOTE_MIN 4    // old sources a wave collects before one hand-over
 #define RTMI_FUSED_MAX_BLOCK 1024  // fused kernel: one workgroup of up to 16 waves per CU
+// Launches the group-of-lanes kernel takes (trace_small_kernel: double precision, one model, travel times without a residual
+// sum): nsrc x G lanes, G = 8 / 16 / 32 / 64 >= nlayers + 1, fill the chip's 256 CUs x 1024 resident lanes at most once.  Measured
+// with 8 interfaces (G = 16; profiles/r04ag/small_kernel_crossover.txt): 20 sources 19.7 us against 27.1 for a lane per source,
+// 2 048: 22 / 30, 8 000 ... 16 384: 32 against 42 (a lane per source) and 44 (the fused kernel); 32 768: 54 against 44.5.
+// RTMI_SMALL_KERNEL_LANES overrides (0: off).
+#ifndef RTMI_SMALL_KERNEL_LANES
+#define RTMI_SMALL_KERNEL_LANES 262144
+#endif
+#include <stdlib.h>
+static inline int rtmi_small_group(int nlayers)
+{
+    const int n1 = nlayers + 1;
+    return n1 <= 8 ? 8 : (n1 <= 16 ? 16 : (n1 <= 32 ? 32 : (n1 <= 64 ? 64 : 0)));
+}
+static inline bool rtmi_small_kernel_takes(int64_t nsrc, int nlayers)
+{
+    static const long long lanes = getenv("RTMI_SMALL_KERNEL_LANES") ? atoll(getenv("RTMI_SMALL_KERNEL_LANES")) : RTMI_SMALL_KERNEL_LANES;
+    const int G = rtmi_small_group(nlayers);
+    return G != 0 && nsrc >= 1 && (long long)nsrc * G <= lanes;
+}
 
 namespace rtmi {
 
@@ -35,6 +55,7 @@ struct TraceArgsT {
     int allow_skip;  // with d_nlayers: d_nlayers[m] == 0 marks an inactive row (no output, partial sums 0)
     int *d_status;   // sticky fault word (host-mapped) or NULL: bit 8 = a d_nlayers[m] out of range
     int skiptab;     // set by the launcher: the layer tables carry the bound of bisection_skip (models of <= 64 interfaces)
+    int lane_per_source;  // 1: never the group-of-lanes kernel (rtmi_set_option("path", 1): the plain kernel, strictly)
 };
 typedef TraceArgsT<double> TraceArgs;
 

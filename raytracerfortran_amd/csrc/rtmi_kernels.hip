@@ -181,6 +181,109 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_kernel(TraceArgsT<T> a)
     }
 }
 
+// (1b) SMALL launches (the reference's own example: NSrc = 20): a GROUP of G lanes per source, one layer term per lane.
+// With a lane per source a launch of a few sources is one wave walking the slowest source's dependent trips alone: every trip
+// evaluates the stack's terms one after the other (eight layers x 35 dependent double-precision instructions: about 1 us), and
+// the kernel took 27 us for 20 sources -- the whole of what the reference needs on one CPU core (27.7 us).  Here lane j of a
+// source's group computes term j of costFunc / costFunc_Prime (:184-221) -- the same guarded forms, the plain operators for the
+// whole wave when any operand is outside the guards -- leaves it in LDS, and every lane of the group adds the terms up IN LAYER
+// ORDER (the stack's full layers, the source's own partial layer, then the zeros of the lanes beyond the stack: x + 0 = x), so
+// f, f' and with them every iterate are the reference's bit for bit; the state machine (lane_advance) runs redundantly in the
+// lanes of a group.  The travel time (:156, :165-166) is summed the same way.  G = 8, 16, 32, 64 >= nlayers + 1.
+template <int G, bool WANT_P>
+__global__ __launch_bounds__(RTMI_BLOCK) void trace_small_kernel(TraceArgsT<double> a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const int nlayers = a.nlayers;
+    const LayerTable<double> t = carve_table(lds_raw, nlayers, false, a.skiptab != 0);
+    // behind the table: one {tf, tp} per lane
+    double2 *scr = reinterpret_cast<double2 *>(lds_raw + ((RTMI_TABLE_ELEMS(nlayers, false, a.skiptab) + 1) & ~(size_t)1));
+    constexpr int SPB = RTMI_BLOCK / G;            // sources per workgroup and trip
+    const int j = threadIdx.x & (G - 1);           // this lane's term
+    const int gb = threadIdx.x & ~(G - 1);         // the group's first lane (index into scr)
+    // the first trip's source is requested before the model is staged (a small launch is all latency)
+    const int64_t k_first = (int64_t)blockIdx.x * SPB + threadIdx.x / G;
+    double R_next = k_first < a.nsrc ? a.d_src_offset[k_first] : 1.0, z_next = k_first < a.nsrc ? a.d_src_depth[k_first] : 1.0;
+    stage_model(t, a.d_vels, a.d_depths, nlayers);
+    const bool use_pred = model_terms_nonneg(t);
+    for (int64_t base = (int64_t)blockIdx.x * SPB; base < a.nsrc; base += (int64_t)gridDim.x * SPB) {
+        const int64_t k = base + threadIdx.x / G;
+        const bool valid = k < a.nsrc;
+        const double R = R_next, z = z_next;
+        {
+            const int64_t kn = k + (int64_t)gridDim.x * SPB;  // the next trip's, in flight during this one
+            R_next = kn < a.nsrc ? a.d_src_offset[kn] : 1.0;
+            z_next = kn < a.nsrc ? a.d_src_depth[kn] : 1.0;
+        }
+        const int nl = which_layer(t, nlayers, z);
+        const bool straight = (nl == 1);  // source in the top layer (:94-97)
+        const bool active = valid && !straight;
+        const int il = active ? nl - 1 : 1;
+        Lane<double> s;
+        lane_setup(s, t, il, R, z);
+        const double p0 = active ? initial_p0(t, il, R, z, active) : 0.0;
+        lane_start(s, p0);
+        if (!active || p0 != p0)
+            s.st = ST_DONE;
+        // this lane's layer of the source's stack: a full layer, the source's own partial layer, or none
+        const bool full = active && j < s.nfull, own = active && j == s.nfull;
+        const int jt = full ? j : t.nul;
+        const double hv = own ? s.hvl : t.HW[jt].hv, vv = own ? s.vvl : t.HW[jt].vv;
+        const int nt_wave = wave_max_i32(active ? s.nfull + 1 : 0);
+        while (__any(s.st != ST_DONE)) {
+            const double x = s.xe, xx = x * x;
+            double tf, tp;
+            const bool ok = layer_term<true>(xx, x, hv, vv, tf, tp) && s.numer_ok && mag_ok(x);
+            if (__any(s.st != ST_DONE && !ok))  // rare: some operand near the ends of the range, 0, Inf or NaN
+                layer_term<false>(xx, x, hv, vv, tf, tp);
+            scr[threadIdx.x] = make_double2(tf, tp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double sf = 0.0, sp = 0.0;
+            for (int i = 0; i < nt_wave; ++i) {  // (a group never straddles a wave)
+                const double2 e = scr[gb + i];
+                sf = sf + e.x;
+                sp = sp + e.y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double f = s.R - sf, fp = -sp;
+            const bool was_init = s.st == ST_INIT;
+            lane_advance(t, s, f, fp, use_pred);
+            if (was_init && s.skip0 && s.st == ST_BIS)  // solvebst entered with f(x1) > 0: idle trips need not be made
+                lane_skip_idle_trips(t, s, il, z - t.D[il - 1]);
+        }
+        // t = sum H_i / (V_i cos_i): this lane's layer, then the sum in layer order
+        {
+            const double pp = s.x * s.x;
+            const double hj = own ? z - t.D[il - 1] : t.H[jt], vj = own ? t.V[il] : t.V[jt], vvj = own ? t.VV[il] : t.VV[jt];
+            const double tj = div_ieee(hj, double(vj * sqrt(1.0 - pp * vvj)));
+            scr[threadIdx.x] = make_double2(tj, 0.0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double tt = 0.0;
+            for (int i = 0; i < nt_wave; ++i)
+                tt = tt + scr[gb + i].x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!s.conv)
+                tt = -999.0;
+            double p_out = s.x;
+            if (straight) {
+                tt = div_ieee(double(sqrt(z * z + R * R)), t.V[0]);
+                p_out = __builtin_nan("");
+            }
+            if (valid && j == 0) {
+                a.d_timeP[k] = tt;
+                if (WANT_P)
+                    a.d_p_final[k] = p_out;
+            }
+        }
+    }
+}
+
 // logL[m] = -(N/2) ln(2 pi) - ( SS/(2 sd^2) + N ln sd )     loglhood.f90:194-196
 __global__ void loglike_kernel(const double *__restrict__ partial, int nparts, const double *__restrict__ sd,
                                int64_t ndat, int nmodels, double *__restrict__ logL, double *__restrict__ ss_out)
@@ -1946,6 +2049,33 @@ static hipError_t launch_trace_t(const rtmi::TraceArgsT<T> &args, int nmodels, i
     {
         const char *tn = std::is_same<T, double>::value ? "double" : "float";
         note_kernel("void rtmi::trace_kernel<%s, %s, %s, %s>(rtmi::TraceArgsT<%s>)", tn, tf(want_p && !want_ss), tf(want_t || !want_ss), tf(want_ss), tn);
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        // small single-model launches without a residual sum: a group of lanes per source (trace_small_kernel)
+        if (!want_ss && want_t && nmodels == 1 && !a.d_nlayers && !a.lane_per_source && rtmi_small_kernel_takes(a.nsrc, a.nlayers)) {
+            const int G = rtmi_small_group(a.nlayers);
+            const int spb = RTMI_BLOCK / G;
+            const int64_t nb = (a.nsrc + spb - 1) / spb;
+            const dim3 sgrid((unsigned)(nb < 4096 ? nb : 4096), 1, 1);
+            const size_t slds = ((RTMI_TABLE_ELEMS(max_nlayers, false, a.skiptab) + 1) & ~(size_t)1) * sizeof(double) + (size_t)RTMI_BLOCK * sizeof(double2);
+            note_kernel("void rtmi::trace_small_kernel<%d, %s>(rtmi::TraceArgsT<double>)", G, tf(want_p));
+#define RTMI_SMALL_LAUNCH(GG)                                                                                          \
+    if (want_p)                                                                                                        \
+        hipLaunchKernelGGL((trace_small_kernel<GG, true>), sgrid, block, slds, stream, a);                              \
+    else                                                                                                               \
+        hipLaunchKernelGGL((trace_small_kernel<GG, false>), sgrid, block, slds, stream, a);
+            if (G == 8) {
+                RTMI_SMALL_LAUNCH(8)
+            } else if (G == 16) {
+                RTMI_SMALL_LAUNCH(16)
+            } else if (G == 32) {
+                RTMI_SMALL_LAUNCH(32)
+            } else {
+                RTMI_SMALL_LAUNCH(64)
+            }
+#undef RTMI_SMALL_LAUNCH
+            return hipGetLastError();
+        }
     }
     if (want_ss && want_t)
         hipLaunchKernelGGL((trace_kernel<T, false, true, true>), grid, block, lds_bytes, stream, a);

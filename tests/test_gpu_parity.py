@@ -154,6 +154,58 @@ def test_bad_inputs_do_not_hang(rt, O):
     assert np.array_equal(t[~ok], ref[~ok], equal_nan=True)  # -999 for NaN data; Inf offset follows the arithmetic
 
 
+def test_small_launches_a_group_of_lanes_per_source(rt, O):
+    """Launches whose sources x group width fit the chip's resident lanes once (the reference's own example has 20 sources, its
+    sampler calls TraceRays with 1e4) take the kernel with a GROUP of lanes per source (csrc/rtmi_kernels.hip::trace_small_kernel: one layer term of costFunc / costFunc_Prime per lane, added up
+    in layer order, subroutineR-quiet.f90:184-221): travel times AND final ray parameters must be the oracle's bits for every
+    group width (8, 16, 32, 64 lanes: models of 1 ... 63 interfaces), for sources in the top layer, exactly on interfaces, below
+    the last interface, with NaN / Inf data, with interfaces out of order -- and equal to the one-lane-per-source kernel that
+    rtmi_set_option("path", 1) selects, strictly."""
+    import torch
+    rng = np.random.default_rng(20260)
+    dev = "cuda"
+    for nl in (1, 2, 3, 7, 8, 9, 15, 16, 20, 31, 32, 47, 63):
+        d = np.sort(rng.uniform(80.0, 9000.0, nl))
+        if nl >= 4 and nl % 2 == 0:
+            d[2] = d[1]                                   # a zero-thickness layer
+        if nl in (9, 47):
+            d[[1, nl - 2]] = d[[nl - 2, 1]]               # interfaces out of order: whichLayer's own scan
+        v = rng.uniform(1500.0, 8000.0, nl + 1)
+        for n in (1, 20, 333, 1024, 4099):
+            off = rng.uniform(0.0, 12000.0, n)
+            dep = rng.uniform(1.0, d.max() + 800.0, n)
+            m = min(max(n - 8, 1), nl)
+            dep[:m] = d[-m:]                              # sources exactly on interfaces (the last one included)
+            if n >= 20:
+                dep[n - 1] = 0.5 * d.min()                # top layer: straight ray
+                off[n - 2] = 0.0                          # vertical ray
+                off[n - 3] = -off[n - 4]                  # negative offset: the mirror ray
+                off[n - 5], dep[n - 6] = np.nan, np.nan
+                off[n - 7] = np.inf
+            t_ref, p_ref, _ = O.oracle_dff(v, d, off, dep, want_p=True)
+            tv, td = torch.tensor(v, device=dev), torch.tensor(d, device=dev)
+            to, tz = torch.tensor(off, device=dev), torch.tensor(dep, device=dev)
+            p = torch.empty(n, dtype=torch.float64, device=dev)
+            t = rt.trace_device(tv, td, to, tz, p_final=p).cpu().numpy()
+            assert np.array_equal(t, t_ref, equal_nan=True), (nl, n, int((t != t_ref).sum()))
+            assert np.array_equal(p.cpu().numpy(), p_ref, equal_nan=True), (nl, n)
+            t2 = rt.trace_device(tv, td, to, tz).cpu().numpy()                         # (the variant without p_final)
+            assert np.array_equal(t2, t_ref, equal_nan=True), (nl, n)
+            if n in (20, 1024):                                                       # the same sources, one lane each
+                try:
+                    rt.set_option("path", 1)
+                    lane = rt.trace_device(tv, td, to, tz).cpu().numpy()
+                    assert rt.last_kernel_name().startswith("void rtmi::trace_kernel<double")
+                finally:
+                    rt.set_option("path", 0)
+                assert np.array_equal(lane, t, equal_nan=True), nl
+                rt.trace_device(tv, td, to, tz)
+                assert "trace_small_kernel" in rt.last_kernel_name(), rt.last_kernel_name()
+            th = rt.dff(v, d, nl, off, dep, n)["timeP"]                               # ... and through the drop-in symbol
+            assert np.array_equal(th, t_ref, equal_nan=True), (nl, n)
+    assert rt.load_library().rtmi_device_status() == 0
+
+
 def test_bad_arguments_raise(rt):
     import torch
     with pytest.raises(rt.RtmiError):
