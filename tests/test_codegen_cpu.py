@@ -35,14 +35,16 @@ LIMITS = {
     # ... and for deeper models: more scratch than round 3's (60 instructions) with the sorted-source form of the body, and still
     # 17 % faster than round 3's on config 4's share (profiles/r04c/pt_timings.txt), where it is the default engine
     "_ZN4rtmi15pt_sweep_kernelILi0ELb1EEE": (150, 128, 210, 100),
+    # small launches, a group of 16 lanes per source (the reference's own example size): no scratch
+    "_ZN4rtmi18trace_small_kernelILi16ELb0EEE": (0, 128, 40, 0),
 }
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_hot_kernels_keep_their_registers_and_stay_out_of_scratch(tmp_path):
     out = tmp_path / "k.s"
-    subprocess.check_call([HIPCC, "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c++17", "--offload-arch=gfx950",
-                           "-S", "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
+    from raytracerfortran_amd import build as B          # the SHIPPED build's flags (incl. -enable-ipra=false, see build.py)
+    subprocess.check_call([HIPCC] + B.CFLAGS + ["-S", "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
     text = out.read_text()
     meta = {}
     for m in re.finditer(r"- \.agpr_count:.*?\.name:\s+(\S+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
