@@ -230,7 +230,8 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_small_kernel(TraceArgsT<doub
         const int jt = full ? j : t.nul;
         const double hv = own ? s.hvl : t.HW[jt].hv, vv = own ? s.vvl : t.HW[jt].vv;
         const int nt_wave = wave_max_i32(active ? s.nfull + 1 : 0);
-        while (__any(s.st != ST_DONE)) {
+        // f, f' at s.xe: this lane's term, then the sums in layer order (every lane of the group ends with the same f, f')
+        auto evaluate = [&](double &f, double &fp) {
             const double x = s.xe, xx = x * x;
             double tf, tp;
             const bool ok = layer_term<true>(xx, x, hv, vv, tf, tp) && s.numer_ok && mag_ok(x);
@@ -248,11 +249,27 @@ __global__ __launch_bounds__(RTMI_BLOCK) void trace_small_kernel(TraceArgsT<doub
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const double f = s.R - sf, fp = -sp;
-            const bool was_init = s.st == ST_INIT;
-            lane_advance(t, s, f, fp, use_pred);
-            if (was_init && s.skip0 && s.st == ST_BIS)  // solvebst entered with f(x1) > 0: idle trips need not be made
+            f = s.R - sf;
+            fp = -sp;
+        };
+        if (__any(s.st != ST_DONE)) {
+            // GetPTime's branch after cf = f(p0), cfp = f'(p0) (:136-153), as the fused kernel's first-evaluation pass takes it
+            double f, fp;
+            evaluate(f, fp);
+            const bool live = s.st == ST_INIT;
+            Lane<double> n = s;
+            lane_advance_init(t, n, f, fp, live);
+            if (live)
+                s = n;
+            if (live && s.st == ST_BIS0 && s.skip0) {  // solvebst entered with f(x1) > 0 without evaluating it; idle trips need not be made
+                lane_enter_bisection(s, false);
                 lane_skip_idle_trips(t, s, il, z - t.D[il - 1]);
+            }
+        }
+        while (__any(s.st != ST_DONE)) {
+            double f, fp;
+            evaluate(f, fp);
+            lane_advance_solve(t, s, f, fp, use_pred);
         }
         // t = sum H_i / (V_i cos_i): this lane's layer, then the sum in layer order
         {
