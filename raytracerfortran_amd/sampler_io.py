@@ -161,14 +161,24 @@ def run_from_files(directory: str, nsweeps: int, nchains: int = 8, seed: int = 1
     # SAVESAMPLE's bookkeeping columns (prjmh_temper_rf.f90:1880-1883; names in raytracerR-export-data-to-MCMC.Rmd:135-146):
     # logPr = the Poisson prior of k (read_input.f90:78-81), tcmp = seconds of computation per step (obj%tcmp, :453), acc_ratio =
     # accepted / proposed perturbations, iacc_bd / irej_bd / iacc_bds = accepted and rejected birth-death moves and accepted
-    # sigma moves.  The reference keeps these counters per chain and writes their values at the time of the sample; the device
-    # sampler keeps them per handle, so every row carries the totals of the run (all local chains).
+    # sigma moves, ic / rank = the chain that wrote the row.  The reference keeps these counters per chain object and writes
+    # their values at the time of the sample; the device sampler keeps them per chain too (rtmi_pt_chain_stats) and they are
+    # read once, after the run: every row of a chain carries that chain's totals of the run.  (The Python engine of the CPU
+    # tests keeps one set of counters for all its chains.)
     st = s.stats
-    acc_ratio = st["acc_mh"] / max(1, st["prop_mh"])
+    per_chain = None
+    if evaluator is None and getattr(s, "sample_chains", None) is not None and len(s.sample_chains) == len(samples):
+        per_chain = s.native.chain_stats()          # [nloc][8]: acc_bd, prop_bd, acc_mh, prop_mh, acc_sd, prop_sd, ...
     with open(out_base + "_voro_sample.txt", "w") as f:
-        for kk, nd, sdv, ll in samples:
-            f.write(sample_row(ll, prior.log_pk(int(kk)), tcmp, nd, sdv, par["NLMX"], acc_ratio=acc_ratio, iacc_bd=st["acc_bd"],
-                               irej_bd=st["prop_bd"] - st["acc_bd"], iacc_bds=st["acc_sd"], ic=1, rank=getattr(s, "rank", 0) + 1) + "\n")
+        for i, (kk, nd, sdv, ll) in enumerate(samples):
+            if per_chain is not None:
+                c = s.sample_chains[i]
+                q = per_chain[c - getattr(s, "first", 0)]
+                cols = dict(acc_ratio=q[2] / max(1, q[3]), iacc_bd=int(q[0]), irej_bd=int(q[1] - q[0]), iacc_bds=int(q[4]), ic=c + 1)
+            else:
+                cols = dict(acc_ratio=st["acc_mh"] / max(1, st["prop_mh"]), iacc_bd=st["acc_bd"], irej_bd=st["prop_bd"] - st["acc_bd"],
+                            iacc_bds=st["acc_sd"], ic=1)
+            f.write(sample_row(ll, prior.log_pk(int(kk)), tcmp, nd, sdv, par["NLMX"], rank=getattr(s, "rank", 0) + 1, **cols) + "\n")
     return {"samples": samples, "sampler": s, "parameters": par}
 
 

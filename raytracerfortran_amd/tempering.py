@@ -467,10 +467,13 @@ class NativeSampler(Sampler):
                         self.native.set_ladder_betas(self.beta_of_level)
         s = self.native.samples()
         out = []
+        self.sample_chains, self.sample_sweeps = [], []   # parallel to the returned list: which (global) chain, after which sweep
         for i in np.lexsort((s["chain"], s["sweep"])):  # the ring is filled through an atomic counter: order by (sweep, chain)
             k = int(s["k"][i])
             nodes = np.column_stack([s["z"][i, :k], s["v"][i, :k]])
             out.append((k, nodes[np.argsort(nodes[:, 0], kind="stable")], float(s["sd"][i]), float(s["logL"][i])))
+            self.sample_chains.append(int(s["chain"][i]))
+            self.sample_sweeps.append(int(s["sweep"][i]))
         self._refresh_stats()
         self._pull(range(self.nloc))
         return out
