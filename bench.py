@@ -671,6 +671,20 @@ def main():
         r = run_pt(rt, torch, dist, rank, world, dev, 10_000, 10, 100, 20)
         cp = chain_parallel_block(r["level"], r["rccl_ranks"], world, r["elapsed"], 100, r["models"], 10_000, r["nloc"],
                                   dist if world > 1 else None, r["red_device"], rccl_info(rt) if rank == 0 else {}, r["engine"], r["exchange"])
+        if world == 1 and rank == 0 and cp is not None:
+            # One rank runs many sweeps per launch with the exchange inside the kernel; several ranks cannot (a pair may straddle
+            # two GPUs): they take one launch per sweep and the all-gather between launches.  The single-rank cost of THAT road,
+            # for whoever compares an N-GPU line with this one:
+            old = os.environ.get("RTMI_PT_MULTI")
+            os.environ["RTMI_PT_MULTI"] = "0"
+            try:
+                r1 = run_pt(rt, torch, dist, rank, world, dev, 10_000, 10, 100, 20)
+                cp["ms_per_sweep_one_launch_per_sweep"] = r1["elapsed"] / 100 * 1e3
+            finally:
+                if old is None:
+                    os.environ.pop("RTMI_PT_MULTI", None)
+                else:
+                    os.environ["RTMI_PT_MULTI"] = old
 
     if rank == 0:
         value = world * n * args.steps / elapsed
