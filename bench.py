@@ -109,7 +109,7 @@ def measured_counters(kernel_substr: str = "fused_kernel"):
             continue
         commit = d.get("build_commit") if isinstance(d.get("build_commit"), str) else None
         for k, c in d.items():
-            if isinstance(c, dict) and kernel_substr in k and "hbm_bytes_per_launch" in c:
+            if isinstance(c, dict) and (k == kernel_substr or (kernel_substr in k and "(" not in kernel_substr)) and "hbm_bytes_per_launch" in c:
                 valu = c.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
                 best = (c["hbm_bytes_per_launch"]["total"], valu, os.path.relpath(path, ROOT), commit)
     return best
@@ -129,7 +129,7 @@ def c2_roofline(n: int, kern_ms: float, kernel_name: str):
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_TT * n,
             "note": "fp64-VALU-bound root-find: 24 B per travel time cannot approach the HBM roof; see DESIGN.md section 4"}
-    tr = measured_traffic()
+    tr = measured_traffic(kernel_name)   # (the summary holds other instantiations too -- the sampler's -- : the exact name)
     if tr is not None and n == 1_000_000:
         roof["traffic"] = tr[0]
         roof["traffic_source"] = ("NOT MEASURED IN THIS RUN: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -139,7 +139,7 @@ def c2_roofline(n: int, kern_ms: float, kernel_name: str):
     peak_lane_instr = FP64_VALU_PEAK_TFLOPS * 1e12 / 2.0
     valu = {"peak_tflops": FP64_VALU_PEAK_TFLOPS, "peak_lane_instr_per_s": peak_lane_instr,
             "note": "fp64 VALU issue is the binding roof (DESIGN.md section 4.2)"}
-    mc = measured_counters()
+    mc = measured_counters(kernel_name)
     if mc is not None and mc[1] and n == 1_000_000 and kern_ms:
         valu["executed_valu_wave_instr_per_launch"] = mc[1]
         valu["executed_frac_of_peak"] = mc[1] * 64.0 / (kern_ms * 1e-3) / peak_lane_instr
