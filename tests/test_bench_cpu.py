@@ -87,8 +87,11 @@ def test_roofline_block_labels_what_was_not_measured(tmp_path, monkeypatch):
     prof = tmp_path / "profiles" / "r99z"
     prof.mkdir(parents=True)
     name = "void rtmi::fused_kernel<double, false, true, false, false, 1, false>(rtmi::FusedArgsT<double>)"
+    other = "void rtmi::fused_kernel<double, false, false, true, false, 1, true>(rtmi::FusedArgsT<double>)"   # the sampler's: same command
     json.dump({"build_commit": "abc1234", name: {"hbm_bytes_per_launch": {"total": 24.6e6},
-                                                  "SQ_INSTS_VALU": {"mean_per_launch": 39.4e6}}}, open(prof / "pmc_summary.json", "w"))
+                                                  "SQ_INSTS_VALU": {"mean_per_launch": 39.4e6}},
+               other: {"hbm_bytes_per_launch": {"total": 2.8e6}, "SQ_INSTS_VALU": {"mean_per_launch": 1.0e6}}},
+              open(prof / "pmc_summary.json", "w"))      # (the counters are looked up by the EXACT name: round 4 once quoted the sampler's)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     roof, valu = bench.c2_roofline(1_000_000, 0.1, name)
     assert roof["kernel"] == name and roof["bound"] == "hbm" and abs(roof["achieved"] - 240.0) < 1e-9
