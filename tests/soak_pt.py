@@ -5,7 +5,9 @@ exchanges and recorded samples; every chain / statistic / ladder / sample bit-id
   per-slot launches, every proposal evaluated over all sources      (RTMI_PT_PERSISTENT=0 RTMI_PT_INCREMENTAL=0)
   per-slot launches, unaffected sources taken from the residual cache (0, 1)
   the persistent launch with the cache                                 (1, 1)
-and the logL of sampled final states equal to the oracle's (1e-9 relative)."""
+and the logL of sampled final states equal to the oracle's (1e-9 relative).  Every other case has ONE CHAIN PER LEVEL (a random
+permutation): there the persistent engine puts the whole run into multi-sweep launches with the exchange inside the kernel
+(csrc/rtmi_kernels.hip::prop_exchange), in two rtmi_pt_run calls with different exchange and record intervals."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,6 +30,9 @@ for case in range(ncases):
     rt.set_sources(off, dep, obs)
     nodes = np.column_stack([[0.0] + list(S.TRUE_D), S.TRUE_V])[: min(7, kmax)]
     pr = T.Prior(kmax=kmax)
+    perm = case % 2 == 1
+    level_perm = rng.permutation(nch)
+    swap2 = int(rng.choice([1, 2]))
     res = {}
     for engine, incr in (("0", "0"), ("0", "1"), ("1", "1")):
         os.environ["RTMI_PT_PERSISTENT"] = engine
@@ -36,10 +41,12 @@ for case in range(ncases):
         for i in range(nch):
             h.set_chain(i, nodes, 0.016, 1.0)
         h.evaluate()
-        nlev = max(2, nch // 2)
-        h.set_ladder(nch, 0, np.arange(nch) % nlev, 1.15 ** -np.arange(float(nlev)))
-        h.sample_buffer(4096)
+        nlev = nch if perm else max(2, nch // 2)
+        h.set_ladder(nch, 0, level_perm if perm else np.arange(nch) % nlev, 1.15 ** -np.arange(float(nlev)))
+        h.sample_buffer(8192)
         h.run(sweeps, 1, None, 3)
+        if perm:
+            h.run(7, swap2, None, 2)
         res[engine + incr] = (h.get_all(), h.stats(), h.get_ladder()[0], h.samples())
         del h
     (a0, s0, l0, m0) = res["00"]
@@ -57,7 +64,8 @@ for case in range(ncases):
         v, d = T.layering(np.column_stack([a1["z"][i, :k], a1["v"][i, :k]]))
         ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v, d, off, dep), a1["sd"][i], stable=True)
         assert abs(a1["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref)), (case, i, a1["logL"][i], ref)
-    print("case %2d ok: %2d chains x %5d sources, kmax %2d, %2d sweeps, models %d, persistent ran: %s" %
-          (case, nch, n, kmax, sweeps, s1["models"], s1["launches"] < s0["launches"]), flush=True)
+    print("case %2d ok: %2d chains x %5d sources, kmax %2d, %2d sweeps, models %d, persistent ran: %s%s" %
+          (case, nch, n, kmax, sweeps, s1["models"], s1["launches"] < s0["launches"],
+           ", one chain per level: %d launches for %d sweeps" % (s1["launches"], sweeps + 7) if perm else ""), flush=True)
 assert rt.load_library().rtmi_device_status() == 0
 print("soak ok: %d cases, persistent engine ran in %d" % (ncases, ran_persistent))
