@@ -509,8 +509,12 @@ void parse_dropin_env_locked(Context &c)
 }
 
 // One slice [k0, k0 + n) of the call on one device.
+// timeP_dev: the caller's (pinned) timeP as the device sees it, or NULL.  With it the kernels write the travel times STRAIGHT
+// into the caller's array over PCIe (posted writes, behind the chunk's arithmetic) and no download is queued at all: round 4's
+// timeline of a 1e6-source call (profiles/r04ao/dropin_timeline.txt) showed the four downloads as blit kernels of 37 us each
+// that no upload overlapped.
 int run_slice(DropinLane &L, int device, const double *vels, const double *depths, int nlayers, const double *src_offset,
-              const double *src_depth, int64_t n, double *timeP, double *p_out, int64_t chunk, const Tuning &tn)
+              const double *src_depth, int64_t n, double *timeP, double *p_out, int64_t chunk, const Tuning &tn, double *timeP_dev = nullptr)
 {
     const int64_t nch = (n + chunk - 1) / chunk;
     int rc = lane_ready(L, device, (size_t)nch);
@@ -527,7 +531,7 @@ int run_slice(DropinLane &L, int device, const double *vels, const double *depth
     if (rc)
         return rc;
     double *d_vels = L.d_model, *d_depths = L.d_model + nlayers + 1;
-    double *d_off = L.d_src, *d_dep = L.d_src + n, *d_t = L.d_src + 2 * n, *d_p = L.d_src + 3 * n;
+    double *d_off = L.d_src, *d_dep = L.d_src + n, *d_t = timeP_dev ? timeP_dev : L.d_src + 2 * n, *d_p = L.d_src + 3 * n;
     HIP_TRY(hipMemcpyAsync(d_vels, vels, (size_t)(nlayers + 1) * sizeof(double), hipMemcpyHostToDevice, L.s_in));
     HIP_TRY(hipMemcpyAsync(d_depths, depths, (size_t)nlayers * sizeof(double), hipMemcpyHostToDevice, L.s_in));
     for (int64_t c = 0; c < nch; ++c) {
@@ -567,13 +571,19 @@ int run_slice(DropinLane &L, int device, const double *vels, const double *depth
             a.d_p_final = p_out ? d_p + k0 : nullptr;
             HIP_TRY(rtmi_launch_trace(&a, 1, nlayers, rtmi_launch_grid_x(m, 1, L.cus), L.s_k));
         }
+        if (timeP_dev && !p_out)
+            continue;  // (nothing to download: the kernel wrote the caller's array)
         HIP_TRY(hipEventRecord(L.ev_k[c], L.s_k));
         HIP_TRY(hipStreamWaitEvent(L.s_out, L.ev_k[c], 0));
-        HIP_TRY(hipMemcpyAsync(timeP + k0, d_t + k0, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, L.s_out));
+        if (!timeP_dev)
+            HIP_TRY(hipMemcpyAsync(timeP + k0, d_t + k0, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, L.s_out));
         if (p_out)
             HIP_TRY(hipMemcpyAsync(p_out + k0, d_p + k0, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, L.s_out));
     }
-    HIP_TRY(hipStreamSynchronize(L.s_out));
+    if (timeP_dev)
+        HIP_TRY(hipStreamSynchronize(L.s_k));
+    if (!timeP_dev || p_out)
+        HIP_TRY(hipStreamSynchronize(L.s_out));
     return RTMI_OK;
 }
 
@@ -686,6 +696,20 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
         registered[2] = hipHostRegister((void *)timeP, n * sizeof(double), hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
     }
+    // RTMI_DROPIN_DIRECT_OUT=1: the bound device's slice writes its travel times straight into the caller's pinned array instead
+    // of queueing downloads.  Measured at 1e6 sources (profiles/r04ao/direct_out.txt): 0.568 against 0.551 ms on arrays that are
+    // reused (the kernels' 8-byte writes cross PCIe less efficiently than the copy engine's bursts), 1.04 against 1.18 ms on newly
+    // allocated arrays (R's .Fortran copies: no second party faults the result's pages in).  Off by default.
+    double *timeP_dev = nullptr;
+    {
+        static const bool direct_out = getenv("RTMI_DROPIN_DIRECT_OUT") && !strcmp(getenv("RTMI_DROPIN_DIRECT_OUT"), "1");
+        if (direct_out && registered[2] && hipHostGetDevicePointer((void **)&timeP_dev, (void *)timeP, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            timeP_dev = nullptr;
+        }
+        if (!direct_out)
+            timeP_dev = nullptr;
+    }
     std::vector<std::future<int>> jobs;
     std::vector<std::string> errs((size_t)nl_use);
     int rc_all = RTMI_OK;
@@ -695,7 +719,8 @@ int trace_host(const double *vels, const double *depths, int nlayers, const doub
         DropinLane *L = g_dropin.lanes[(size_t)i].get();
         auto job = [=, &tn, &errs, &p]() {
             const int r = run_slice(*L, dev, vels, depths, nlayers, src_offset + k0, src_depth + k0, k1 - k0, timeP + k0,
-                                    want_p ? p.data() + k0 : nullptr, dropin_chunk_for(k1 - k0), tn);
+                                    want_p ? p.data() + k0 : nullptr, dropin_chunk_for(k1 - k0), tn,
+                                    (i == 0 && timeP_dev) ? timeP_dev + k0 : nullptr);
             if (r)
                 errs[(size_t)i] = g_err;  // the worker thread's message
             return r;
