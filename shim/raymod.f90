@@ -173,6 +173,13 @@ module rtmi_sampler
          integer(c_int), intent(out) :: k(*)
          real(c_double), intent(out) :: depths(*), vels(*), sd(*), logL(*), ss(*), beta(*)   ! depths/vels: (kmax, nchains)
       end function rtmi_pt_get_all
+      ! the acceptance counters chain by chain (the reference's obj%iaccept_bd ..., prjmh_temper_rf.f90:1880-1883): stats(8, nchains) =
+      ! accepted / proposed birth-death, accepted / proposed perturbations, accepted / proposed sigma, models decided, discarded
+      integer(c_int) function rtmi_pt_chain_stats(h, stats) bind(C, name="rtmi_pt_chain_stats")
+         import :: c_ptr, c_int, c_int64_t
+         type(c_ptr), value :: h
+         integer(c_int64_t), intent(out) :: stats(8, *)
+      end function rtmi_pt_chain_stats
       integer(c_int) function rtmi_comm_unique_id(id) bind(C, name="rtmi_comm_unique_id")
          import :: c_int, c_char
          character(kind=c_char), intent(out) :: id(*)       ! RTMI_COMM_ID_BYTES bytes: MPI_BCAST them from rank 0
