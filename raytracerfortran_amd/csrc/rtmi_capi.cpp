@@ -114,10 +114,20 @@ static Tuning &tuning_locked()
     return t;
 }
 
+// A sampler handle whose source set is below the batch path's own threshold still wants the fused kernel's sampler form (exact
+// sums -> the speculative persistent sweep): its entry points set this for the calling thread (rtmi_pt.hip::PathScope), and
+// every routing decision below sees force_path = 2 unless the caller forced a path itself.
+static thread_local int g_path_override = 0;
+void set_path_override(int v) { g_path_override = v; }
+int path_override() { return g_path_override; }
+
 Tuning tuning_snapshot()
 {
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    return tuning_locked();
+    Tuning t = tuning_locked();
+    if (g_path_override && t.force_path == 0)
+        t.force_path = g_path_override;
+    return t;
 }
 
 Context &ctx()

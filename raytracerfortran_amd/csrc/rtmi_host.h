@@ -63,6 +63,8 @@ struct Tuning {
     int diag_fine;                 // ... including the per-trip clocks and counters
 };
 Tuning tuning_snapshot();
+void set_path_override(int v);  // (thread-local) 2: route as if the fused path were forced, unless the caller forced one; 0: off
+int path_override();
 
 // Sticky fault word of the device code (pinned host memory mapped into the device).  `dev` is NULL until the first
 // successful allocation; status_word_for(stream) refuses (returns NULL and records an error) when the word would have

@@ -259,6 +259,7 @@ struct rtmi_pt {
     int sweep_parity = 0;
     rtmi::PtSweepArgs *d_wprop = nullptr;  // device copy of the proportional engine's words ...
     rtmi::PtSweepArgs wprop;               // ... and the host's (the words of a multi-sweep launch are rewritten before it)
+    bool prefer_fused = false;             // the handle's launches take the fused kernel although its source set is below the batch path's threshold (rtmi_pt_create)
     bool levels_perm = false;              // the ladder has one chain per level, levels 0 .. nct - 1 (set_ladder): a chain's level IS its position
     double *d_mb_logl = nullptr;           // [2][nct] | the exchange's mailboxes (multi-sweep launches, rtmi_kernels.hip::prop_exchange)
     int *d_mb_chain = nullptr;             // [2][nct] |
@@ -270,6 +271,19 @@ struct rtmi_pt {
 };
 
 namespace {
+
+// the calling thread routes this handle's launches to the fused kernel (rtmi_host.h::set_path_override) while in scope
+struct PathScope {
+    int old;
+    explicit PathScope(bool on) : old(path_override())
+    {
+        if (on)
+            set_path_override(2);
+    }
+    ~PathScope() { set_path_override(old); }
+    PathScope(const PathScope &) = delete;
+    PathScope &operator=(const PathScope &) = delete;
+};
 
 int blocks_for(int n) { return (n + PT_BLOCK - 1) / PT_BLOCK; }
 size_t pack_lds(const rtmi_pt *h)
@@ -602,6 +616,14 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         h->use_persistent = strcmp(e, "0") != 0;
         h->engine = h->use_persistent ? 1 : 0;
     }
+    // Small source sets (the reference's own example has 20 sources): the batch path would take the plain kernel, whose sums are
+    // doubles -- no speculative step, no persistent sweep, a launch pair per slot: 0.45 ms per sweep of 32 chains at 20 sources,
+    // 0.81 ms at 1500.  The handle takes the fused kernel's sampler form instead where its chains fit the persistent engine
+    // (0.35 ms per sweep at 20 ... 1500 sources, profiles/r04ar/pt_small_sets.txt); rtmi_set_option("path", ...) still decides
+    // when it is set, and RTMI_PT_SMALL_FUSED=0 keeps the plain kernel.
+    h->prefer_fused = !batch_is_fused(c.set_n) && nchains <= c.cus && h->use_persistent &&
+                      !(getenv("RTMI_PT_SMALL_FUSED") && !strcmp(getenv("RTMI_PT_SMALL_FUSED"), "0"));
+    PathScope path_scope(h->prefer_fused);
     const bool fused_path = batch_is_fused(c.set_n);  // which kernel the handle's likelihood launches will take
     // Speculative proposals (rtmi_pt_dev.hpp::pt_step_spec) need the exact sums of the fused kernel's sampler form: with them
     // a chain is bit for bit the chain of the one-at-a-time step.  RTMI_PT_SPECULATE = rows per chain (0: the one-at-a-time
@@ -990,6 +1012,7 @@ int rtmi_pt_evaluate(rtmi_pt *h)
     if (!h)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_evaluate: NULL handle");
     std::lock_guard<std::mutex> lk(h->mu);
+    PathScope path_scope(h->prefer_fused);
     HIP_TRY(hipSetDevice(h->device));
     const dim3 g(blocks_for(h->nchains)), b(64);
     hipLaunchKernelGGL(pt_pack_current_kernel, g, b, pack_lds(h), h->stream, h->d);
@@ -1239,6 +1262,7 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     if (!h || nsweeps < 0 || swap_every < 0 || record_every < 0)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    PathScope path_scope(h->prefer_fused);
     HIP_TRY(hipSetDevice(h->device));
     if (record_every > 0 && !h->d_s_count)
         return fail(RTMI_ERR_BAD_ARG, "rtmi_pt_run: record_every > 0 needs rtmi_pt_sample_buffer first");

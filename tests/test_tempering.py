@@ -890,6 +890,56 @@ def test_multi_sweep_launch_with_the_exchange_inside_the_kernel_is_exact():
 
 
 @pytest.mark.gpu
+def test_small_source_sets_take_the_speculative_sweep(kat):
+    """The reference's own example has 20 sources: far below the batch path's threshold for the fused kernel, whose sampler form
+    (exact sums) the speculative persistent sweep needs.  A sampler handle takes that form on its own where its chains fit the
+    persistent engine (csrc/rtmi_pt.hip::rtmi_pt_create, prefer_fused) -- rows per chain > 1, many sweeps per launch -- and the
+    bookkeeping stays the oracle's: logL of every chain's final state to 1e-9 relative; RTMI_PT_SMALL_FUSED=0 keeps the plain
+    kernel (one proposal at a time)."""
+    import raytracerfortran_amd as rt
+    from raytracerfortran_amd import raymod
+    from oracle import oracle as O
+    rt.load_library(); rt.init(0)
+    m = kat["model"]
+    off, dep, obs = (np.asarray(kat[k], float) for k in ("test_1_src_offset", "test_1_src_depth", "test_1_obs_RT"))
+    rt.set_sources(off, dep, obs)
+    nodes = np.column_stack([[0.0] + m["depths"], m["vels"]])
+    for small_fused in ("1", "0"):
+        old = os.environ.get("RTMI_PT_SMALL_FUSED")
+        os.environ["RTMI_PT_SMALL_FUSED"] = small_fused
+        try:
+            h = raymod.NativeChains(8, 11, 20, T.Prior(), seed=5)
+        finally:
+            if old is None:
+                os.environ.pop("RTMI_PT_SMALL_FUSED", None)
+            else:
+                os.environ["RTMI_PT_SMALL_FUSED"] = old
+        for i in range(8):
+            h.set_chain(i, nodes, 0.02, 1.0)
+        h.evaluate()
+        h.set_ladder(8, 0, np.arange(8), 1.3 ** -np.arange(8.0))
+        h.run(40, 1, None, 0)                                            # (the handle's engine trial is in here)
+        l0 = h.stats()["launches"]
+        h.run(64, 1, None, 0)
+        info, st = h.speculation(), h.stats()
+        if small_fused == "1":
+            assert info["rows"] > 1 and info["sorted_sources"], info
+            if info["engine"] == 1:
+                assert st["launches"] - l0 <= 2, (st["launches"], l0)    # many sweeps per launch
+        else:
+            assert info["rows"] == 1, info
+        assert st["acc_mh"] > 0
+        a = h.get_all()
+        for i in range(8):
+            k = int(a["k"][i])
+            v2, d2 = T.layering(np.column_stack([a["z"][i, :k], a["v"][i, :k]]))
+            ref = O.oracle_loglhood_rt(obs, O.oracle_dff(v2, d2, off, dep), a["sd"][i], stable=True)
+            assert abs(a["logL"][i] - ref) <= 1e-9 * max(1.0, abs(ref)), (small_fused, i)
+        del h
+    assert rt.load_library().rtmi_device_status() == 0
+
+
+@pytest.mark.gpu
 def test_device_sampler_keeps_a_sentinel_residual_finite(golden_batches):
     """A source the reference gives up on (-999, subroutineR-quiet.f90:167-169) enters SUM(DresRT**2) as (t_obs + 999)^2 -- about
     1e6 s^2 -- and the reference, the batch API and the host sampler all sum that as a finite number (loglhood.f90:165-199).  The
