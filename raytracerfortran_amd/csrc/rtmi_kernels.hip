@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
         dg[0] = dg[1] = dg[2] = dg[3] = dg[4] = 0ull;
         dg[5] = __builtin_amdgcn_s_memrealtime();
     }
-    if (wp->xcd_map == 77) {  // (diagnostic, RTMI_PT_POISON_LDS: what the likelihood body reads of LDS it has not written shows up as NaN)
+    if (wp->poison_lds) {  // (diagnostic, RTMI_PT_POISON_LDS: what the likelihood body reads of LDS it has not written shows up as NaN)
         for (int q = threadIdx.x; q < lds_ctl / 8; q += blockDim.x)
             reinterpret_cast<unsigned long long *>(lds_raw)[q] = 0x7FF8DEADBEEF0000ull + (unsigned)q;
         __syncthreads();

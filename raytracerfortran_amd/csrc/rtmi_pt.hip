@@ -706,7 +706,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         w.nspec = h->nspec;
         w.walloc = h->d_walloc;
         w.stats = h->d_qstats;
-        w.xcd_map = getenv("RTMI_PT_POISON_LDS") ? 77 : 0;  // (diagnostic: pt_sweep_prop_kernel fills its LDS with NaN patterns first)
+        w.poison_lds = getenv("RTMI_PT_POISON_LDS") ? 1 : 0;  // (diagnostic: pt_sweep_prop_kernel fills its LDS with NaN patterns first)
         w.nsweeps = 1;
         h->wprop = w;
         ok = hipMalloc((void **)&h->d_wprop, sizeof w) == hipSuccess && hipMemcpy(h->d_wprop, &w, sizeof w, hipMemcpyHostToDevice) == hipSuccess;
