@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTMI_VERSION 300      /* 0.3.0 */
+#define RTMI_VERSION 400      /* 0.4.0 */
 #define RTMI_MAX_LAYERS 1024  /* interfaces per model the kernels accept */
 
 /* Status codes of the rtmi_* entry points (0 = success). */

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built):
     assert sorted(raymod.SIGNATURES) == syms
     lib7 = ctypes.CDLL(built.LIB7)
     assert hasattr(lib7, "dff_")  # the 7-argument flavour (subroutineR.f90:405)
-    assert raymod.load_library().rtmi_version() == 300
+    assert raymod.load_library().rtmi_version() == 400
 
 
 def test_gpu_code_object_is_gfx950(built):
