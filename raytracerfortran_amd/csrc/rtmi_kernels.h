@@ -170,9 +170,10 @@ struct PtSweepArgs {
     int *level;                  // [nct]
     const double *beta_of_level; // [nct]
     long long *swstats;          // [2] accepted, proposed
-    double *mb_logl;             // [2][nct] mailbox of a level: logL of the chain that sits on it, after its sweep of the round
-    int *mb_chain;               // [2][nct] ... and which chain that is
-    unsigned long long *mb_seq;  // [2][nct] round + 1 once the entry is there (the two halves alternate with the round)
+    double *mb_logl;             // [4][nct] mailbox of a level: logL of the chain that sits on it, after its sweep of the round
+    int *mb_chain;               // [4][nct] ... and which chain that is
+    unsigned long long *mb_seq;  // [4][nct] round + 1 once the entry is there (set round mod 4: an entry is overwritten four rounds later,
+                                 //          by when its reader is provably through with it -- see prop_exchange_post)
     int s_cap;                   // sample ring (rtmi_pt_sample_buffer) or 0
     int *s_count;
     long long *s_meta;

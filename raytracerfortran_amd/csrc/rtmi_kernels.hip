@@ -1472,17 +1472,19 @@ __device__ __noinline__ void pt_step_call(const rtmi_pt_dev::PtDev *dp, int chai
     }
 }
 
-__device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int chain, int begin, int wg_total)
+__device__ __noinline__ bool pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int chain, int begin, int wg_total, double beta_alt)
 {
     const rtmi_pt_dev::PtDev d = *dp;  // (called by the 64 lanes of wave 0: the lane groups take the window's slots side by side)
+    bool diverged = false;
     if (threadIdx.x < 64) {
         if (d.K <= 16)
-            rtmi_pt_dev::pt_step_spec<16>(d, chain, begin, 0, wg_total);
+            diverged = rtmi_pt_dev::pt_step_spec<16>(d, chain, begin, 0, wg_total, beta_alt);
         else if (d.K <= 32)
-            rtmi_pt_dev::pt_step_spec<32>(d, chain, begin, 0, wg_total);
+            diverged = rtmi_pt_dev::pt_step_spec<32>(d, chain, begin, 0, wg_total, beta_alt);
         else
-            rtmi_pt_dev::pt_step_spec<64>(d, chain, begin, 0, wg_total);
+            diverged = rtmi_pt_dev::pt_step_spec<64>(d, chain, begin, 0, wg_total, beta_alt);
     }
+    return diverged;
 }
 
 // ---- the speculative sweep, workgroups dealt to the chains IN PROPORTION TO THEIR SLOTS ------------------------------------
@@ -1501,7 +1503,7 @@ __device__ __noinline__ void pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int
 // (The kernel around the likelihood body keeps next to nothing in registers: the body is at its register limit, and whatever
 // lives across it is paid for in spills inside its loops.  The layout, the handshakes and the steps are real calls; what a
 // workgroup has to remember between them -- its chain, its row, the pass -- sits in LDS.)
-enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_BEGIN, PROP_SWDONE, PROP_WORDS = 8 };
+enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_BEGIN, PROP_SWDONE, PROP_XPEND, PROP_XLP, PROP_WORDS = 12 };
 
 __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, volatile int *ctl)
 {
@@ -1522,6 +1524,42 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
     // XCD-major order, so that a chain's workgroups -- which pass model rows, residual rows and sums to each other every pass
     // -- sit on one XCD where its share allows
     const long long vb = (nwg & 7) == 0 ? (long long)(blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : (long long)blockIdx.x;
+    if ((nwg & 7) == 0 && (nchains & 7) == 0 && nchains <= 64 && nwg >= nchains) {
+        // NO CHAIN ON TWO XCDs: the chains are dealt to the XCDs first (nchains / 8 each, in order), and an XCD's workgroups to ITS
+        // chains by weight.  With one proportional layout over the whole launch a chain at an XCD boundary had its workgroups on two
+        // L2s -- every hand-over of the pass through memory -- and ran a fifth slower than the others (RTMI_PT_QSTATS=2,
+        // profiles/r04aw/chains2.txt: own share 109 against 95 us, 45 against 31 us waiting for its workgroups); in a multi-sweep
+        // launch every other chain then waits for that one, round after round (120 us per sweep at its partner's mailbox).
+        const int cx = nchains >> 3, wx = nwg >> 3;
+        const int c = lane;
+        int wc = c < nchains ? wts[c] : 0;
+        wc = (c < nchains && wc < 1) ? 1 : wc;
+        int incl = wc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += o;
+        }
+        const int x = c < nchains ? c / cx : 0, gs = x * cx;             // the chain's XCD, the first chain of that XCD
+        const int sb = __shfl(incl, gs > 0 ? gs - 1 : 0, 64);            // (every lane takes part in the shuffle: its source lane must)
+        const int before = gs > 0 ? sb : 0;                               // weights of the XCDs before
+        const int Wx = __shfl(incl, gs + cx - 1, 64) - before;           // weights of this XCD's chains
+        const int P = incl - wc - before;                                 // ... of its chains before this one
+        const long long Rx = wx - cx;
+        const long long first = (long long)x * wx + (c - gs) + (Rx * P) / Wx;
+        const long long next = (c - gs) + 1 < cx ? (long long)x * wx + (c - gs) + 1 + (Rx * (P + wc)) / Wx : (long long)(x + 1) * wx;
+        if (c < nchains && vb >= first && vb < next) {
+            ctl[PROP_CHAIN] = c;
+            ctl[PROP_ROW] = (int)(vb - first);
+            ctl[PROP_GX] = (int)(next - first);
+            ctl[PROP_BASE] = (int)__hip_atomic_load(wp->count + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl[PROP_BEGIN] = 1;   // the chain's next step is the first of a sweep
+            ctl[PROP_SWDONE] = 0;  // sweeps of this launch the chain has completed
+            ctl[PROP_XPEND] = 0;   // > 0: the exchange after that sweep of the launch is posted, not completed yet
+        }
+        return;
+    }
     long long carry = 0;
     for (int c0 = 0; c0 < nchains; c0 += 64) {
         const int c = c0 + lane;
@@ -1544,6 +1582,7 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
             ctl[PROP_BASE] = (int)__hip_atomic_load(wp->count + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ctl[PROP_BEGIN] = 1;   // the chain's next step is the first of a sweep
             ctl[PROP_SWDONE] = 0;  // sweeps of this launch the chain has completed
+            ctl[PROP_XPEND] = 0;   // > 0: the exchange after that sweep of the launch is posted, not completed yet
         }
         carry += __shfl(incl, 63, 64);
     }
@@ -1557,36 +1596,72 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
 // says round + 1; both evaluate the same rule on the same numbers and each moves ITSELF.  A chain waits for nobody but its partner,
 // so the chains drift apart by a sweep or so and nobody waits for the unluckiest chain of every sweep (profiles/r04z/chains_4.txt:
 // a chain's sweep takes 535 us on average, the slowest of 32 took 690 us, sweep after sweep).
-__device__ __noinline__ void prop_exchange(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done, int *d_status)
+//
+// IN TWO HALVES.  Even so a chain spent a third of its time waiting for its partner (RTMI_PT_QSTATS=2, profiles/r04au/chains.txt:
+// 190 of 595 us per sweep).  But nothing of a sweep's FIRST pass depends on the temperature: proposals, bounds, model rows and
+// their likelihoods do not, and a trivial move's ratio is lp + beta (L* - logL) with L* - logL = 0 exactly at a sweep's start.  So
+// a chain POSTS its mailbox entry when its sweep is complete (prop_exchange_post), lays out and evaluates the first window of its
+// next sweep, and COMPLETES the exchange (prop_exchange_complete: wait for the partner's entry, decide, move, record the sample --
+// the chain's state is still that of the completed sweep: the first step of a sweep decides nothing) right before the first
+// DECISION of that sweep.  The wait for the partner hides behind a pass.
+// Mailbox sets: round mod 4.  A chain's entry of round R is overwritten by the entry of round R + 4 of whoever sits on that level
+// then, who by then has completed round R + 3 >= R + 2 -- the round in which the pairs are those of round R again, and whose
+// completion needs the entry of a chain that had itself completed round R + 1, hence R: the reader of the old entry is through
+// with it.  (With two sets a chain whose next sweep happens to need no pass at all could overwrite its entry before a slower
+// partner, busy with its own first pass, had read it.)  A sequence word that is AHEAD of its reader is a fault, never a guess.
+// Returns the partner's level (the chain's temperature after the exchange is its own or that level's), -1 without a partner.
+__device__ __noinline__ int prop_exchange_post(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done)
+{
+    const long long total = wp->sweeps_done + done;  // sweeps of the handle, this one included
+    if (!(wp->swap_every > 0 && total % wp->swap_every == 0))
+        return -1;
+    const unsigned long long rnd = wp->round + (unsigned long long)(total / wp->swap_every - wp->sweeps_done / wp->swap_every) - 1ull;
+    const int nct = wp->nct, par = (int)(rnd & 1ull), buf = (int)(rnd & 3ull);
+    const int L = __hip_atomic_load(wp->level + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int a = ((L - par) & 1) == 0 ? L : L - 1;
+    if (!(a >= par && a + 1 < nct))
+        return -1;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long mine = __hip_atomic_load(reinterpret_cast<unsigned long long *>(dp->logL + chain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(wp->mb_logl + (size_t)buf * nct + L), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wp->mb_chain + (size_t)buf * nct + L, chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_store(wp->mb_seq + (size_t)buf * nct + L, rnd + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return L == a ? a + 1 : a;
+}
+
+__device__ __noinline__ void prop_exchange_complete(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done, int *d_status)
 {
     namespace R = rtmi_pt_rules;
     const int lane = threadIdx.x & 63;
-    const long long total = wp->sweeps_done + done;  // sweeps of the handle, this one included
+    const long long total = wp->sweeps_done + done;  // sweeps of the handle, the completed one included
     int lev = 0;
     if (wp->swap_every > 0 && total % wp->swap_every == 0) {
         int newlev = -1;
         if (lane == 0) {
             const unsigned long long rnd = wp->round + (unsigned long long)(total / wp->swap_every - wp->sweeps_done / wp->swap_every) - 1ull;
-            const int nct = wp->nct, par = (int)(rnd & 1ull), buf = par;
+            const int nct = wp->nct, par = (int)(rnd & 1ull), buf = (int)(rnd & 3ull);
             const int L = __hip_atomic_load(wp->level + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int a = ((L - par) & 1) == 0 ? L : L - 1;
             newlev = L;
             if (a >= par && a + 1 < nct) {
-                const double mine = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(dp->logL + chain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                wp->mb_logl[(size_t)buf * nct + L] = mine;
-                wp->mb_chain[(size_t)buf * nct + L] = chain;
-                __threadfence();
-                __hip_atomic_store(wp->mb_seq + (size_t)buf * nct + L, rnd + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // (this chain's own entry -- what prop_exchange_post wrote: the chain's logL has not changed since)
+                const double mine = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(wp->mb_logl + (size_t)buf * nct + L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 const int Lp = L == a ? a + 1 : a;
                 unsigned long long *sq = wp->mb_seq + (size_t)buf * nct + Lp;
                 unsigned long long got = 0ull;
                 int polls = 0;
                 bool ok = true;
+                const unsigned long long tw0 = wp->stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #pragma unroll 1
                 for (;;) {
                     got = __hip_atomic_load(sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (got >= rnd + 1ull)
+                    if (got >= rnd + 1ull) {
+                        if (wp->stats)  // (diagnostic: how long the chain waited for its partner's entry)
+                            wp->stats[16 + 8 * (size_t)chain + 7] += __builtin_amdgcn_s_memrealtime() - tw0;
                         break;
+                    }
                     if (__hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++polls > (1 << 23)) {
                         ok = false;
                         break;
@@ -1594,7 +1669,7 @@ __device__ __noinline__ void prop_exchange(const rtmi_pt_dev::PtDev *dp, const P
                     __builtin_amdgcn_s_sleep(16);
                 }
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                if (!ok || got != rnd + 1ull) {  // never expected: the partner is gone, or a round ahead of its mailbox's reader
+                if (!ok || got != rnd + 1ull) {  // never expected: the partner is gone, or its mailbox is rounds ahead of its reader
                     __hip_atomic_store(wp->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (d_status)
                         atomicOr(d_status, 16);
@@ -1650,8 +1725,8 @@ __device__ __noinline__ void prop_exchange(const rtmi_pt_dev::PtDev *dp, const P
 }
 
 // The leading workgroup's part of a pass (wave 0 calls): the chain's step(s), the weight of the chain for the next launch's
-// layout once a sweep is complete -- and, in a launch of several sweeps, the exchange and the next sweep's first step right
-// behind it -- then the flag.  Leaves fin | nact in LDS.
+// layout once a sweep is complete -- and, in a launch of several sweeps, its half of the exchange and the next sweep's first
+// step right behind it -- then the flag.  Leaves fin | nact in LDS.
 __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, volatile int *ctl, int pass, unsigned int epoch,
                                        int parity, int *d_status)
 {
@@ -1660,26 +1735,61 @@ __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSwe
     int guard = 0, fin_ = 0, nact_ = 0;
 #pragma unroll 1
     for (;;) {
-        pt_step_spec_call(dp, chain, ctl[PROP_BEGIN], gx);
+        // While the exchange of the sweep before is posted but not completed the chain's temperature is its own or its partner's
+        // level's: the step is asked to go on only where its decisions come out the same under both (pt_step_spec, beta_alt);
+        // where they do not -- or where the T = 1 sample of that sweep has to be taken from the state the chain still has -- the
+        // exchange is completed first (the wait for the partner).
+        double beta_alt = __builtin_nan("");
+        if (ctl[PROP_XPEND] != 0 && !ctl[PROP_BEGIN]) {
+            const int xd = ctl[PROP_XPEND], lp = ctl[PROP_XLP];
+            const bool record_due = wp->record_every > 0 && wp->s_cap > 0 && (wp->s0 + xd) % wp->record_every == 0;
+            if (record_due || lp < 0) {
+                prop_exchange_complete(dp, wp, chain, xd, d_status);
+                ctl[PROP_XPEND] = 0;
+                __threadfence();
+                __builtin_amdgcn_s_dcache_inv();
+            } else {
+                beta_alt = wp->beta_of_level[lp];
+            }
+        }
+        // (begin = 2: the first step of a sweep whose temperature is not known yet -- it decides nothing, and lays its window
+        // out only where that does not depend on the temperature: pt_step_spec)
+        const bool diverged = pt_step_spec_call(dp, chain, ctl[PROP_BEGIN] ? (ctl[PROP_XPEND] != 0 ? 2 : 1) : 0, gx, beta_alt);
+        if (__any(diverged)) {  // a decision depends on which temperature it is: nothing was written; the partner, then again
+            prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status);
+            ctl[PROP_XPEND] = 0;
+            __threadfence();
+            __builtin_amdgcn_s_dcache_inv();
+            continue;
+        }
         __threadfence();                  // the rows are out before the flag; and this workgroup (one L1) reads them afresh, too
         __builtin_amdgcn_s_dcache_inv();  // ... and so does a step that follows at once (the chain's words are wave-uniform: scalar loads)
         ctl[PROP_BEGIN] = 0;
         fin_ = __hip_atomic_load(dp->fin + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (fin_) {
+            if (ctl[PROP_XPEND] != 0) {  // the chain must know its level before it posts the next round's entry
+                prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status);
+                ctl[PROP_XPEND] = 0;
+                __threadfence();
+                __builtin_amdgcn_s_dcache_inv();
+            }
             const int done = ctl[PROP_SWDONE] + 1;
             ctl[PROP_SWDONE] = done;
             if ((threadIdx.x & 63) == 0)  // the weight of this chain in the NEXT launch's layout
                 wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             if (nsw > 1) {
-                prop_exchange(dp, wp, chain, done, d_status);
-                __threadfence();
-                __builtin_amdgcn_s_dcache_inv();
+                const int lp = prop_exchange_post(dp, wp, chain, done);
                 if (done < nsw && __hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    ctl[PROP_BEGIN] = 1;  // the next sweep at once
+                    ctl[PROP_XPEND] = done;  // completed when a decision needs the temperature, at the latest when the next sweep is complete
+                    ctl[PROP_XLP] = lp;
+                    ctl[PROP_BEGIN] = 1;     // the next sweep's first window at once
                     guard = 0;
                     continue;
                 }
+                prop_exchange_complete(dp, wp, chain, done, d_status);  // the launch's last sweep: now
+                __threadfence();
+                __builtin_amdgcn_s_dcache_inv();
             }
             break;
         }
@@ -1771,11 +1881,14 @@ __global__ __launch_bounds__(RTMI_FUSED_MAX_BLOCK) void pt_sweep_prop_kernel(Fus
                 const unsigned long long life = __builtin_amdgcn_s_memrealtime() - dg[5];
                 __hip_atomic_fetch_add(st + 5, life, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (ctl[PROP_ROW] == 0) {  // per chain (its leading workgroup): ticks, sweeps, the longest, passes
-                    unsigned long long *q = st + 8 + 4 * (size_t)ctl[PROP_CHAIN];
+                    unsigned long long *q = st + 16 + 8 * (size_t)ctl[PROP_CHAIN];
                     q[0] += life;
                     q[1] += (unsigned long long)(wp->nsweeps > 1 ? wp->nsweeps : 1);
                     q[2] = life > q[2] ? life : q[2];
                     q[3] += dg[3];
+                    q[4] += dg[0];   // the leading workgroup's own likelihood shares
+                    q[5] += dg[2];   // ... its waits for the chain's other workgroups
+                    q[6] += dg[1];   // ... its steps (in a multi-sweep launch: with the exchanges and their waits)
                 }
             }
             return;

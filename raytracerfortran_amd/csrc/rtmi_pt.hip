@@ -261,9 +261,9 @@ struct rtmi_pt {
     rtmi::PtSweepArgs wprop;               // ... and the host's (the words of a multi-sweep launch are rewritten before it)
     bool prefer_fused = false;             // the handle's launches take the fused kernel although its source set is below the batch path's threshold (rtmi_pt_create)
     bool levels_perm = false;              // the ladder has one chain per level, levels 0 .. nct - 1 (set_ladder): a chain's level IS its position
-    double *d_mb_logl = nullptr;           // [2][nct] | the exchange's mailboxes (multi-sweep launches, rtmi_kernels.hip::prop_exchange)
-    int *d_mb_chain = nullptr;             // [2][nct] |
-    unsigned long long *d_mb_seq = nullptr;  // [2][nct] |
+    double *d_mb_logl = nullptr;           // [4][nct] | the exchange's mailboxes (multi-sweep launches, rtmi_kernels.hip::prop_exchange_post / _complete)
+    int *d_mb_chain = nullptr;             // [4][nct] |
+    unsigned long long *d_mb_seq = nullptr;  // [4][nct] |
     std::vector<rtmi::PtInc> inc0;   // (one-at-a-time step) the rows of the residual slab never change: a chain's record as reset by rtmi_pt_set_chain
     unsigned int epoch = 0;          // slots run through the persistent kernel so far
     int kbound = 1;  // upper bound of max k over the chains, known to the host without a read-back
@@ -694,8 +694,8 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         ok = hipMemcpy(h->d_walloc, w0.data(), w0.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok && h->spec && getenv("RTMI_PT_QSTATS"))  // diagnostic: where the workgroups' time goes (printed by rtmi_pt_run)
-        ok = hipMalloc((void **)&h->d_qstats, (16 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess &&   // + per chain: ticks, sweeps, longest, passes; + 8 phase clocks of the step
-             hipMemset(h->d_qstats, 0, (16 + 4 * nc) * sizeof(unsigned long long)) == hipSuccess;
+        ok = hipMalloc((void **)&h->d_qstats, (16 + 8 * nc) * sizeof(unsigned long long)) == hipSuccess &&   // [8 .. 16): phase clocks of the step; then per chain: ticks, sweeps, longest, passes, leader's shares / waits / steps
+             hipMemset(h->d_qstats, 0, (16 + 8 * nc) * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {
         rtmi::PtSweepArgs w;
         memset(&w, 0, sizeof w);
@@ -806,7 +806,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
     d.ncdf = ncdf;
     d.nspec = h->nspec;
     d.spec_step = h->spec ? 1 : 0;
-    d.dbg = (h->d_qstats && getenv("RTMI_PT_QSTATS") && atoi(getenv("RTMI_PT_QSTATS")) >= 3) ? h->d_qstats + 8 + 4 * nc : nullptr;
+    d.dbg = (h->d_qstats && getenv("RTMI_PT_QSTATS") && atoi(getenv("RTMI_PT_QSTATS")) >= 3) ? h->d_qstats + 8 : nullptr;
     d.spec_prop = (getenv("RTMI_PT_SPEC_PROP") ? atoi(getenv("RTMI_PT_SPEC_PROP")) : 0) ? 1 : 0;
     d.part_stride = pstride;
     d.gx_launch = h->gx_launch;
@@ -1080,12 +1080,12 @@ int rtmi_pt_set_ladder(rtmi_pt *h, int nchains_total, int first_chain, const int
             seen[(size_t)level[i]] = 1;
         }
         h->levels_perm = perm;
-        HIP_TRY(hipMalloc((void **)&h->d_mb_logl, 2 * nct * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&h->d_mb_chain, 2 * nct * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&h->d_mb_seq, 2 * nct * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(h->d_mb_logl, 0, 2 * nct * sizeof(double)));
-        HIP_TRY(hipMemset(h->d_mb_chain, 0, 2 * nct * sizeof(int)));
-        HIP_TRY(hipMemset(h->d_mb_seq, 0, 2 * nct * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&h->d_mb_logl, 4 * nct * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&h->d_mb_chain, 4 * nct * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&h->d_mb_seq, 4 * nct * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(h->d_mb_logl, 0, 4 * nct * sizeof(double)));
+        HIP_TRY(hipMemset(h->d_mb_chain, 0, 4 * nct * sizeof(int)));
+        HIP_TRY(hipMemset(h->d_mb_seq, 0, 4 * nct * sizeof(unsigned long long)));
     }
     std::vector<double> b((size_t)h->nchains);
     for (int c = 0; c < h->nchains; ++c)
@@ -1359,12 +1359,12 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
     }
     const int rc = finish(h);  // the one synchronisation of the call
     if (!rc && h->d_qstats) {
-        std::vector<unsigned long long> stv(16 + 4 * (size_t)h->nchains);
+        std::vector<unsigned long long> stv(16 + 8 * (size_t)h->nchains);
         unsigned long long *st = stv.data();
         HIP_TRY(hipMemcpy(st, h->d_qstats, stv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(h->d_qstats, 0, stv.size() * sizeof(unsigned long long)));
         if (h->d.dbg) {
-            const unsigned long long *q = st + 8 + 4 * (size_t)h->nchains;
+            const unsigned long long *q = st + 8;
             const double n = q[6] ? (double)q[6] : 1.0;
             fprintf(stderr, "rtmi:   the step, per call (%llu calls, %.2f slots per window): loads %.1f us, decisions %.1f, sigma + state %.1f, the window's rounds %.1f, "
                             "prefix + words + stores out %.1f; whole call %.1f us\n", q[6], (double)q[7] / n, 0.01 * q[0] / n, 0.01 * q[1] / n, 0.01 * q[2] / n,
@@ -1378,12 +1378,14 @@ int rtmi_pt_run(rtmi_pt *h, int nsweeps, int swap_every, rtmi_comm *comm, int re
             HIP_TRY(hipMemcpy(kk.data(), h->d.k, kk.size() * sizeof(int), hipMemcpyDeviceToHost));
             double mean_all = 0.0, mean_max = 0.0;
             for (int c = 0; c < h->nchains; ++c) {
-                const unsigned long long *q = st + 8 + 4 * (size_t)c;
-                const double m = q[1] ? 0.01 * (double)q[0] / (double)q[1] : 0.0;
+                const unsigned long long *q = st + 16 + 8 * (size_t)c;
+                const double m = q[1] ? 0.01 * (double)q[0] / (double)q[1] : 0.0, np = q[3] ? (double)q[3] : 1.0;
                 mean_all += m / h->nchains;
                 mean_max = m > mean_max ? m : mean_max;
-                fprintf(stderr, "rtmi:   chain %2d beta %.4f k %2d: sweep %.0f us on average, longest %.0f us, %.2f passes per sweep\n", c, beta[c], kk[c], m,
-                        0.01 * (double)q[2], q[1] ? (double)q[3] / (double)q[1] : 0.0);
+                fprintf(stderr, "rtmi:   chain %2d beta %.4f k %2d: sweep %.0f us on average, longest %.0f us, %.2f passes per sweep; per pass its leading "
+                                "workgroup: own share %.0f us, then %.0f us waiting for the chain's others; steps (+ exchanges) %.0f us per sweep, of which %.0f us waiting for the partner's mailbox\n", c, beta[c], kk[c], m,
+                        0.01 * (double)q[2], q[1] ? (double)q[3] / (double)q[1] : 0.0, 0.01 * (double)q[4] / np, 0.01 * (double)q[5] / np,
+                        q[1] ? 0.01 * (double)q[6] / (double)q[1] : 0.0, q[1] ? 0.01 * (double)q[7] / (double)q[1] : 0.0);
             }
             fprintf(stderr, "rtmi:   mean over the chains %.0f us, slowest chain on average %.0f us\n", mean_all, mean_max);
         }

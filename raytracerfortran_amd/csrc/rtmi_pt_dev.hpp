@@ -455,7 +455,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 // residuals (r2cur, or the pending accepted proposal's row) and write rows of their own; the two sets of proposal rows
 // alternate whenever a proposal is accepted, so no row is read and written in the same pass, and exactly one row of a pass
 // (the first) moves the pending residuals to r2cur.
-// begin: first step of a sweep.  eval: decide an evaluation of the current state (rtmi_pt_evaluate) and propose nothing.
+// begin: first step of a sweep (2: and the chain's temperature may still change, see below).  eval: decide an evaluation of the
+// current state (rtmi_pt_evaluate) and propose nothing.
 // wg_total: > 0 workgroups the chain's rows share in the next pass (they are dealt to the evaluated rows round-robin),
 // 0 = every row has d.gx_launch of its own (per-slot engine: one batched launch over all rows).
 // Called by ALL 64 lanes of a wave for one chain.
@@ -463,7 +464,8 @@ __device__ __forceinline__ void pt_step_group(const PtDev &d, const int c, int d
 #define PT_WIN_MAX 16    // slots of a window
 
 template <int G>
-__device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const int begin, const int eval, const int wg_total)
+__device__ __forceinline__ bool pt_step_spec(const PtDev &d, const int c, const int begin, const int eval, const int wg_total,
+                                             const double beta_alt = __builtin_nan(""))
 {
     namespace R = rtmi_pt_rules;
     constexpr int NG = 64 / G;                              // slots worked on side by side
@@ -541,6 +543,13 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     };
     const double lstar_prev = loglike_of_ss(ss, sd);
 
+    // beta_alt (not NaN): the chain's exchange of the sweep before is posted, not completed (rtmi_kernels.hip::prop_lead): its
+    // temperature is `beta` or `beta_alt`.  The step goes on WITHOUT the partner as long as every decision it takes comes out the
+    // same under both -- a proposal that is rejected by e^-30 under one temperature is rejected under its neighbour's as well --
+    // and otherwise writes nothing and returns true: the caller completes the exchange and calls again.
+    const bool two_betas = beta_alt == beta_alt;
+    bool diverged = false;
+    bool write_cache_valid = false, write_state = false;   // (what the decisions change is written after that check)
     // ---- decisions of the window (prjmh_temper_rf.f90:697-706, :742-751): every group its entry, then the first in order ---
     bool taken = false;
     int acc_slot = 1 << 30;   // slot of the accepted entry (the window's other slots count up to it)
@@ -564,6 +573,15 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         const bool acc = mine && (act == 2 || (lr == lr && !(u_acc >= exp(lr))));
         const unsigned long long macc = __ballot(acc) & leads;
         const int gfirst = macc ? (__ffsll((long long)macc) - 1) / G : NG;   // the first group (= entry, = slot) that accepts
+        if (two_betas) {  // the same under the other temperature the chain may turn out to have?
+            double lr2 = e_lp[r] + (logl_new - (after ? lstar_prev : logL)) * beta_alt;
+            if (lr2 > 50.0)
+                lr2 = 50.0;
+            const bool acc2 = mine && (act == 2 || (lr2 == lr2 && !(u_acc >= exp(lr2))));
+            const unsigned long long macc2 = __ballot(acc2) & leads;
+            const int gfirst2 = macc2 ? (__ffsll((long long)macc2) - 1) / G : NG;
+            diverged = diverged || gfirst2 != gfirst;
+        }
         // entries decided in this round: the groups up to the accepting one
         const bool decided = mine && g <= gfirst;
         const unsigned long long mdec = __ballot(decided && act != 2) & leads;
@@ -634,18 +652,10 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
             wbuf ^= 1;
             if (!cache_ok) {  // (without a valid cache every proposal is evaluated in full: this one was)
                 cache_ok = 1;
-                if (lane == 0)
-                    d.cache_valid[c] = 1;
+                write_cache_valid = true;
             }
         }
-        if ((taken || bta) && g == 0) {
-            if (lead)
-                d.k[c] = k;
-            if (i < k && i < K) {
-                d.z[row] = zi;
-                d.v[row] = vi;
-            }
-        }
+        write_state = taken || bta != 0u;
     }
 
     if (d.dbg) {
@@ -666,7 +676,14 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
                 if (lr > 50.0)
                     lr = 50.0;
                 const double u_acc = R::draw_uniform(rng, nsw, R::SLOT_SIGMA, R::DRAW_ACCEPT);
-                if (lr == lr && !(u_acc >= exp(lr))) {
+                const bool acc_sd = lr == lr && !(u_acc >= exp(lr));
+                if (two_betas) {
+                    double lr2 = (logl_new - logL) * beta_alt;
+                    if (lr2 > 50.0)
+                        lr2 = 50.0;
+                    diverged = diverged || acc_sd != (lr2 == lr2 && !(u_acc >= exp(lr2)));
+                }
+                if (acc_sd) {
                     sd = sd_new;
                     logL = logl_new;
                     d_st[4] += 1;
@@ -675,6 +692,22 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
         }
         nsw += 1ull;  // the chain's sweep is complete
         fin = 1;
+    }
+    // a trivial move's ratio is lp + beta (L* - logL); logL is always the likelihood of (SS, sd) by this very formula, so the
+    // difference is 0 and beta drops out -- checked, not assumed, while the temperature is open
+    if (two_betas && !eval && !fin && !(loglike_of_ss(ss, sd) == logL))
+        diverged = true;
+    if (diverged)
+        return true;   // nothing was written: the caller completes the exchange and calls again
+    if (write_cache_valid && lane == 0)
+        d.cache_valid[c] = 1;
+    if (write_state && g == 0) {
+        if (lead)
+            d.k[c] = k;
+        if (i < k && i < K) {
+            d.z[row] = zi;
+            d.v[row] = vi;
+        }
     }
     if (lane == 0) {
         d.sd[c] = sd;
@@ -704,7 +737,12 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
     int kp = k;
     double lpath = logL;                // ... and its logL
     const double lstar = loglike_of_ss(ss, sd);
-    const bool propose_on = !eval && !fin;
+    // begin == 2: the chain's temperature is not known yet (its exchange is posted, not completed: rtmi_kernels.hip::prop_lead).
+    // Nothing of a window depends on it but a trivial move's ratio lp + beta (L* - logL) -- and at the start of a sweep
+    // L* - logL is exactly 0 (logL was last set by this very formula), so beta drops out.  Should it not be (never seen), the
+    // window is left to the next call, which comes after the exchange.
+    const bool defer = begin == 2 && !(lstar == lpath);
+    const bool propose_on = !eval && !fin && !defer;
     // Rows of this window.  A sweep lasts as long as the chain with the most nodes takes, a pass costs a fixed latency (the step
     // and the slowest sources of a share) on top of its throughput, and the launch's workgroups are dealt to the chains in
     // proportion to their slots: with windows in the same proportion every chain needs about the same NUMBER of passes and a
@@ -1000,6 +1038,7 @@ __device__ __forceinline__ void pt_step_spec(const PtDev &d, const int c, const 
             atomicAdd(d.dbg + 5, t - tk0);   // the whole call
         }
     }
+    return false;
 }
 
 }  // namespace rtmi_pt_dev
