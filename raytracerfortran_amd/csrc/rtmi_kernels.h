@@ -156,6 +156,7 @@ struct PtSweepArgs {
     unsigned long long *stats;  // NULL, or [8] diagnostic sums (RTMI_PT_QSTATS): ticks in the likelihood, in steps, waiting; passes
     int *walloc;           // speculative form: [2][nchains] weights (slots of the chain's sweep) by which the launch's workgroups
     int parity;            // are dealt to the chains: read from walloc[parity], rewritten for the next sweep in walloc[1 - parity]
+    int adapt;             // multi-sweep launches: a chain's weight for the next launch = its workgroups x the share of the launch it was not waiting
     int poison_lds;        // diagnostic (RTMI_PT_POISON_LDS): pt_sweep_prop_kernel fills its dynamic LDS with NaN patterns before it starts
     // ---- launches of SEVERAL sweeps with the temperature exchange inside the kernel (every chain of the ladder local, one chain
     // per level): a chain that has completed its sweep meets only its PARTNER of the round -- through a mailbox per level --

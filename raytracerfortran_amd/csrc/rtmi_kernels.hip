@@ -1503,7 +1503,7 @@ __device__ __noinline__ bool pt_step_spec_call(const rtmi_pt_dev::PtDev *dp, int
 // (The kernel around the likelihood body keeps next to nothing in registers: the body is at its register limit, and whatever
 // lives across it is paid for in spills inside its loops.  The layout, the handshakes and the steps are real calls; what a
 // workgroup has to remember between them -- its chain, its row, the pass -- sits in LDS.)
-enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_BEGIN, PROP_SWDONE, PROP_XPEND, PROP_XLP, PROP_WORDS = 12 };
+enum { PROP_GO = 0, PROP_CHAIN, PROP_ROW, PROP_GX, PROP_BASE, PROP_NACT, PROP_BEGIN, PROP_SWDONE, PROP_XPEND, PROP_XLP, PROP_T0, PROP_WAIT, PROP_WORDS = 12 };
 
 __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, volatile int *ctl)
 {
@@ -1557,6 +1557,8 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
             ctl[PROP_BEGIN] = 1;   // the chain's next step is the first of a sweep
             ctl[PROP_SWDONE] = 0;  // sweeps of this launch the chain has completed
             ctl[PROP_XPEND] = 0;   // > 0: the exchange after that sweep of the launch is posted, not completed yet
+            ctl[PROP_T0] = (int)(unsigned int)__builtin_amdgcn_s_memrealtime();
+            ctl[PROP_WAIT] = 0;
         }
         return;
     }
@@ -1583,6 +1585,8 @@ __device__ __noinline__ void prop_layout(const PtSweepArgs *wp, int parity, vola
             ctl[PROP_BEGIN] = 1;   // the chain's next step is the first of a sweep
             ctl[PROP_SWDONE] = 0;  // sweeps of this launch the chain has completed
             ctl[PROP_XPEND] = 0;   // > 0: the exchange after that sweep of the launch is posted, not completed yet
+            ctl[PROP_T0] = (int)(unsigned int)__builtin_amdgcn_s_memrealtime();
+            ctl[PROP_WAIT] = 0;
         }
         carry += __shfl(incl, 63, 64);
     }
@@ -1631,7 +1635,8 @@ __device__ __noinline__ int prop_exchange_post(const rtmi_pt_dev::PtDev *dp, con
     return L == a ? a + 1 : a;
 }
 
-__device__ __noinline__ void prop_exchange_complete(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done, int *d_status)
+__device__ __noinline__ void prop_exchange_complete(const rtmi_pt_dev::PtDev *dp, const PtSweepArgs *wp, int chain, int done, int *d_status,
+                                                    volatile int *ctl)
 {
     namespace R = rtmi_pt_rules;
     const int lane = threadIdx.x & 63;
@@ -1653,13 +1658,15 @@ __device__ __noinline__ void prop_exchange_complete(const rtmi_pt_dev::PtDev *dp
                 unsigned long long got = 0ull;
                 int polls = 0;
                 bool ok = true;
-                const unsigned long long tw0 = wp->stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
                 for (;;) {
                     got = __hip_atomic_load(sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (got >= rnd + 1ull) {
+                        const unsigned long long tw = __builtin_amdgcn_s_memrealtime() - tw0;
+                        ctl[PROP_WAIT] += (int)tw;  // (100 MHz ticks: the launch's weights for the next one, prop_lead)
                         if (wp->stats)  // (diagnostic: how long the chain waited for its partner's entry)
-                            wp->stats[16 + 8 * (size_t)chain + 7] += __builtin_amdgcn_s_memrealtime() - tw0;
+                            wp->stats[16 + 8 * (size_t)chain + 7] += tw;
                         break;
                     }
                     if (__hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++polls > (1 << 23)) {
@@ -1744,7 +1751,7 @@ __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSwe
             const int xd = ctl[PROP_XPEND], lp = ctl[PROP_XLP];
             const bool record_due = wp->record_every > 0 && wp->s_cap > 0 && (wp->s0 + xd) % wp->record_every == 0;
             if (record_due || lp < 0) {
-                prop_exchange_complete(dp, wp, chain, xd, d_status);
+                prop_exchange_complete(dp, wp, chain, xd, d_status, ctl);
                 ctl[PROP_XPEND] = 0;
                 __threadfence();
                 __builtin_amdgcn_s_dcache_inv();
@@ -1756,7 +1763,7 @@ __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSwe
         // out only where that does not depend on the temperature: pt_step_spec)
         const bool diverged = pt_step_spec_call(dp, chain, ctl[PROP_BEGIN] ? (ctl[PROP_XPEND] != 0 ? 2 : 1) : 0, gx, beta_alt);
         if (__any(diverged)) {  // a decision depends on which temperature it is: nothing was written; the partner, then again
-            prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status);
+            prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status, ctl);
             ctl[PROP_XPEND] = 0;
             __threadfence();
             __builtin_amdgcn_s_dcache_inv();
@@ -1769,15 +1776,29 @@ __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSwe
         nact_ = __hip_atomic_load(dp->nact + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (fin_) {
             if (ctl[PROP_XPEND] != 0) {  // the chain must know its level before it posts the next round's entry
-                prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status);
+                prop_exchange_complete(dp, wp, chain, ctl[PROP_XPEND], d_status, ctl);
                 ctl[PROP_XPEND] = 0;
                 __threadfence();
                 __builtin_amdgcn_s_dcache_inv();
             }
             const int done = ctl[PROP_SWDONE] + 1;
             ctl[PROP_SWDONE] = done;
-            if ((threadIdx.x & 63) == 0)  // the weight of this chain in the NEXT launch's layout
-                wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if ((threadIdx.x & 63) == 0) {
+                // The weight of this chain in the NEXT launch's layout.  One sweep per launch: its slots (2 k + 1).  A launch of
+                // several sweeps moves at the pace of its slowest chain and the others wait at their partners' mailboxes: the
+                // chain asks for workgroups in proportion to the ones it has x the time it was NOT waiting (RTMI_PT_ADAPT=0: slots).
+                int wnext = 2 * __hip_atomic_load(dp->k + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                if (nsw > 1 && wp->adapt && done >= nsw) {
+                    const unsigned int dur = (unsigned int)__builtin_amdgcn_s_memrealtime() - (unsigned int)ctl[PROP_T0];
+                    const unsigned int waited = (unsigned int)ctl[PROP_WAIT];
+                    const unsigned int busy = dur > waited ? dur - waited : 1u;
+                    // (per mille of the launch, times the workgroups it had: sums stay far below 2^31 for any launch)
+                    const unsigned long long pm = (1000ull * busy) / (dur ? dur : 1u);
+                    wnext = (int)((unsigned long long)gx * (pm < 1 ? 1 : pm));
+                }
+                if (nsw == 1 || done >= nsw)
+                    wp->walloc[(size_t)(1 - parity) * wp->nchains + chain] = wnext;
+            }
             if (nsw > 1) {
                 const int lp = prop_exchange_post(dp, wp, chain, done);
                 if (done < nsw && __hip_atomic_load(wp->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -1787,7 +1808,7 @@ __device__ __noinline__ void prop_lead(const rtmi_pt_dev::PtDev *dp, const PtSwe
                     guard = 0;
                     continue;
                 }
-                prop_exchange_complete(dp, wp, chain, done, d_status);  // the launch's last sweep: now
+                prop_exchange_complete(dp, wp, chain, done, d_status, ctl);  // the launch's last sweep: now
                 __threadfence();
                 __builtin_amdgcn_s_dcache_inv();
             }

@@ -706,6 +706,7 @@ rtmi_pt *rtmi_pt_create(int nchains, int ld_model, int64_t ndata, const rtmi_pt_
         w.nspec = h->nspec;
         w.walloc = h->d_walloc;
         w.stats = h->d_qstats;
+        w.adapt = (getenv("RTMI_PT_ADAPT") && !strcmp(getenv("RTMI_PT_ADAPT"), "0")) ? 0 : 1;
         w.poison_lds = getenv("RTMI_PT_POISON_LDS") ? 1 : 0;  // (diagnostic: pt_sweep_prop_kernel fills its LDS with NaN patterns first)
         w.nsweeps = 1;
         h->wprop = w;
