@@ -178,6 +178,33 @@ def chain_parallel_block(level, rccl_ranks, world, elapsed_s, sweeps, models, ns
             "swap_every": 1, "exchange": exchange, "engine": engine, **rccl_info}
 
 
+def fenced(fn, limit_s, on_timeout):
+    """Run fn() under a fence: -> (fn(), False), or ({"error": ...}, True) if it raised.  If it has not returned after limit_s
+    seconds, a watchdog thread calls on_timeout({"error": ...}) (rank 0: write the line without the block) and ends THIS process
+    with exit code 0 -- every rank carries the same fence, so a set of ranks waiting for each other all leave."""
+    import threading
+    import traceback
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(limit_s):
+            if on_timeout is not None:
+                on_timeout({"error": "no result after %.0f s (RTMI_BENCH_CP_TIMEOUT_S): block abandoned, ranks ended" % limit_s})
+            sys.stdout.flush()
+            os._exit(0)
+
+    threading.Thread(target=watch, daemon=True).start()
+    try:
+        return fn(), False
+    except BaseException as e:  # a rank that fails must still let rank 0 write the headline
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        sys.stderr.write("[bench] chain_parallel failed:\n" + traceback.format_exc())
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}, True
+    finally:
+        done.set()
+
+
 def cpu_baseline(v, d, off, dep, budget_s: float = 12.0):
     """Time the CPU restatement on this host: all cores (threads over source slices; the C code
     holds no shared state and ctypes releases the GIL) and one core.  Bounded to ~budget_s."""
@@ -666,8 +693,34 @@ def main():
     # The path's one exchange step, made visible to the scaling run (BASELINE configs 3/4): after the C2
     # measurement every rank runs 100 sweeps of its 32 tempered chains over 1e4 shared sources through rtmi_pt_run with the
     # LIBRARY's communicator -- one RCCL all-gather of 8 B per chain per swap round -- and the line carries what came of it.
-    cp = None
-    if not args.no_chain_parallel:
+    # The block is fenced: the headline above is already measured when it starts, and the library's RCCL exchange has never run
+    # on more than one GPU before the driver's scaling run -- an error in it, or ranks that wait for each other for ever, must
+    # cost the line its `chain_parallel` object (which then says what happened), not the line.
+    def line(cp, full=True):
+        """Rank 0's one JSON line.  `full` = with the drop-in figures and the CPU baseline (left out when the fence writes the
+        line: the card may be the thing that hangs)."""
+        value = world * n * args.steps / elapsed
+        res = {
+            "metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "ranks": world, "devices": args.devices, "collective_backend": args.backend,
+            "config": {"workload": "C2: single dff forward, 1e6 sources x 8 interfaces (9 velocities, one LVZ), "
+                                   "seed 12345; BASELINE.json configs[1]",
+                       "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
+        }
+        res["roofline"], res["valu_fp64"] = c2_roofline(n, kern_ms, kernel_name)
+        if check is not None:
+            res["check_vs_oracle"] = check
+        if cp is not None:
+            res["chain_parallel"] = cp
+        if full and world == 1 and not args.no_dropin:
+            res["dropin"] = dropin_figures(rt, v, d, off, dep, dt.cpu().numpy())
+        if full and world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(v, d, off, dep)
+        return json.dumps(res)
+
+    def chain_parallel():
         r = run_pt(rt, torch, dist, rank, world, dev, 10_000, 10, 100, 20)
         cp = chain_parallel_block(r["level"], r["rccl_ranks"], world, r["elapsed"], 100, r["models"], 10_000, r["nloc"],
                                   dist if world > 1 else None, r["red_device"], rccl_info(rt) if rank == 0 else {}, r["engine"], r["exchange"])
@@ -685,28 +738,18 @@ def main():
                     os.environ.pop("RTMI_PT_MULTI", None)
                 else:
                     os.environ["RTMI_PT_MULTI"] = old
+        return cp
 
+    cp, broken = None, False
+    if not args.no_chain_parallel:
+        cp, broken = fenced(chain_parallel, float(os.environ.get("RTMI_BENCH_CP_TIMEOUT_S", "240")),
+                            (lambda c: print(line(c, full=False), flush=True)) if rank == 0 else None)
     if rank == 0:
-        value = world * n * args.steps / elapsed
-        res = {
-            "metric": "travel-times/sec", "value": value, "unit": "travel-times/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "ranks": world, "devices": args.devices, "collective_backend": args.backend,
-            "config": {"workload": "C2: single dff forward, 1e6 sources x 8 interfaces (9 velocities, one LVZ), "
-                                   "seed 12345; BASELINE.json configs[1]",
-                       "nsrc_per_gpu": n, "nlayers": 8, "sharding": "sources per rank, no collective"},
-        }
-        res["roofline"], res["valu_fp64"] = c2_roofline(n, kern_ms, kernel_name)
-        if check is not None:
-            res["check_vs_oracle"] = check
-        if cp is not None:
-            res["chain_parallel"] = cp
-        if world == 1 and not args.no_dropin:
-            res["dropin"] = dropin_figures(rt, v, d, off, dep, dt.cpu().numpy())
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(v, d, off, dep)
-        print(json.dumps(res), flush=True)
+        print(line(cp, full=not broken), flush=True)
+    if broken:
+        # peers may still sit in the exchange this rank left: no collective tear-down, every rank leaves on its own
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

@@ -122,3 +122,26 @@ def test_kernel_name_of_the_line_is_the_one_rocprof_saw():
     assert fmt, "the launcher no longer records the kernel it dispatches"
     want = fmt.group(1) % ("double", "false", "true", "false", "false", 1, "double")   # C2: travel times only, row tables
     assert want in fused, (want, fused)
+
+
+def test_fence_of_the_chain_parallel_block(tmp_path):
+    """bench.fenced: a block that raises costs the line its object, not the line; a block that never returns is abandoned by
+    the watchdog, which lets rank 0 write the line and ends the process with exit code 0 (every rank carries the same fence)."""
+    import subprocess
+    import bench
+    out, broken = bench.fenced(lambda: {"ok": 1}, 30.0, None)
+    assert out == {"ok": 1} and not broken
+
+    def boom():
+        raise RuntimeError("rtmi_comm_create failed: unhandled system error")
+    out, broken = bench.fenced(boom, 30.0, None)
+    assert broken and "rtmi_comm_create failed" in out["error"] and out["error"].startswith("RuntimeError")
+    # the hang: a child process whose block sleeps for ever
+    code = ("import sys, time, json; sys.path.insert(0, %r); import bench\n"
+            "bench.fenced(lambda: time.sleep(600), 1.0, lambda c: print(json.dumps({'value': 1.0, 'chain_parallel': c}), flush=True))\n"
+            "print('not reached')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "not reached" not in p.stdout
+    assert "abandoned" in json.loads(lines[0])["chain_parallel"]["error"]
