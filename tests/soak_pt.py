@@ -17,7 +17,7 @@ from oracle import oracle as O
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rt.load_library(); rt.init(0)
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "99")))  # SOAK_SEED: other shapes than the committed runs saw
 ran_persistent = 0
 for case in range(ncases):
     nch = int(rng.choice([8, 16, 32, 40, 64]))
