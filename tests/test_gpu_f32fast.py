@@ -144,3 +144,30 @@ def test_fast_path_negative_offsets_are_mirror_rays():
     ref = O.oracle_dff(v, d, -off, dep)                   # the reference on the mirrored sources
     ok = (ref != -999.0) & (tm != -999.0)
     assert np.median(np.abs(tm[ok] - ref[ok])) < 1e-6 and np.quantile(np.abs(tm[ok] - ref[ok]), 0.999) < 1e-4
+
+
+@pytest.mark.gpu
+def test_fast_path_on_the_pinned_pairs():
+    """tests/golden/f32fast_pairs.json: 24 sources where the reference (oracle/_ref, recorded in the fixture) returns -999, 24 where
+    it accepts a time off by 2 ms ... 3.6 s, 16 ordinary ones.  The fast path returns the time of the actual ray on ALL of them --
+    no sentinel, within single-precision roundoff of the converged solution recorded next to the reference's answer -- and agrees
+    with the reference where the reference's iteration behaved.  A change of the kernel's sentinel rule (include/rtmi.h) or of its
+    start value on the hard sources moves this test; the CPU side (test_oracle_golden.py) keeps the reference's column honest."""
+    import json
+    import os
+    from conftest import ROOT
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "f32fast_pairs.json")))
+    worst = {"sentinel": 0.0, "gross": 0.0, "agree": 0.0}
+    for c in fx["cases"]:
+        v, d, off, dep = (np.array(c[k], np.float64) for k in ("vels", "depths", "src_offset", "src_depth"))
+        ref, conv = np.array(c["t_reference"]), np.array(c["t_converged"])
+        t = run_fast(v, d, off, dep).astype(np.float64)
+        assert not (t == -999.0).any(), (c["kind"], t)
+        e = np.abs(t - conv)
+        assert e.max() < 3e-6, (c["kind"], e.max(), t, conv)                      # single-precision roundoff of a time of seconds
+        if c["kind"] == "agree":
+            assert np.abs(t - ref).max() < 1e-4                                  # 0.1 m short of the root is <= 6.7e-5 s
+        else:
+            assert (np.abs(t - ref) > 1e-3).all()                                # by design NOT the reference's answer here
+        worst[c["kind"]] = max(worst[c["kind"]], float(e.max()))
+    print("fast fp32 vs converged on the pinned pairs, max |dt|:", worst)

@@ -157,3 +157,37 @@ def test_config4_full_size_fixture(name):
     z, w = c4_fixture()
     t = O.oracle_dff(z[f"{name}__vels"], z[f"{name}__depths"], w["off"], w["dep"])
     assert compare_times(t, z[f"{name}__timeP"], tol=1e-12) == 0.0
+
+
+def test_pairs_where_the_fast_fp32_path_and_the_reference_differ():
+    """tests/golden/f32fast_pairs.json (made by make_f32fast_golden.py from oracle/_ref = the reference itself): the oracle gives the
+    reference's answer on every pair, bit for bit -- the -999 of GetPTime (subroutineR-quiet.f90:112-173), the grossly wrong iterate
+    solve accepts through its inverted test (:327-330) -- and the converged solution of costFunc = 0 (:184-202) is the other column.
+    The GPU side of the fixture is tests/test_gpu_f32fast.py::test_fast_path_on_the_pinned_pairs."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from f32fast_ref import converged_times
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "f32fast_pairs.json")))
+    seen = {"sentinel": 0, "gross": 0, "agree": 0}
+    for c in fx["cases"]:
+        v, d, off, dep = (np.array(c[k], np.float64) for k in ("vels", "depths", "src_offset", "src_depth"))
+        for a in (v, d, off, dep):
+            assert (a.astype(np.float32).astype(np.float64) == a).all()          # what the kernel is handed is exactly this
+        ref, conv = np.array(c["t_reference"]), np.array(c["t_converged"])
+        got = O.oracle_dff(v, d, off, dep)
+        assert (got == ref).all(), (c["kind"], got, ref)
+        if O.have_ref():
+            assert (O.ref_dff(v, d, off, dep) == ref).all()
+        tc, _ = converged_times(v, d, off, dep)
+        assert np.abs(tc - conv).max() < 1e-12
+        if c["kind"] == "sentinel":
+            assert (ref == -999.0).all() and np.isfinite(conv).all() and (conv > 0).all()
+        elif c["kind"] == "gross":
+            assert (ref != -999.0).all() and (np.abs(ref - conv) > 1e-3).all()
+        else:
+            assert (np.abs(ref - conv) < 6.7e-5).all()                          # the reference's stopping tolerance: 0.1 m / 1500 m/s
+        seen[c["kind"]] += ref.size
+    assert seen == {"sentinel": 24, "gross": 24, "agree": 16}
