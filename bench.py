@@ -742,7 +742,7 @@ def main():
 
     cp, broken = None, False
     if not args.no_chain_parallel:
-        cp, broken = fenced(chain_parallel, float(os.environ.get("RTMI_BENCH_CP_TIMEOUT_S", "240")),
+        cp, broken = fenced(chain_parallel, float(os.environ.get("RTMI_BENCH_CP_TIMEOUT_S", "120")),
                             (lambda c: print(line(c, full=False), flush=True)) if rank == 0 else None)
     if rank == 0:
         print(line(cp, full=not broken), flush=True)
